@@ -1,0 +1,348 @@
+"""ctypes binding of libffp.so (include/ffp.h) + thin numpy-facing handles.
+
+The library is the product: if it is missing or cannot be loaded every entry point raises — there is no Python or
+PyTorch fallback for any operator.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import weights_io
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libffp.so")
+
+PREC_F32, PREC_F16 = 0, 1
+CHAN_AS_BGR, CHAN_AS_RGB = 0, 1
+PP_NMS, PP_GREEDYNMM = 0, 1
+METRIC_IOU, METRIC_IOS = 0, 1
+PP_TYPES = {"NMS": PP_NMS, "GREEDYNMM": PP_GREEDYNMM}
+METRICS = {"IOU": METRIC_IOU, "IOS": METRIC_IOS}
+
+_lib = None
+
+
+class FfpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libffp error {code}: {msg}")
+        self.code = code
+
+
+def _p(t):
+    return C.POINTER(t)
+
+
+_SIGS = {
+    "ffp_last_error": (C.c_char_p, []),
+    "ffp_version": (C.c_int, []),
+    "ffp_device_count": (C.c_int, [_p(C.c_int)]),
+    "ffp_slice_bboxes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _p(C.c_int32), C.c_int, _p(C.c_int32)]),
+    "ffp_letterbox_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, _p(C.c_int32)]),
+    "ffp_det_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_void_p)]),
+    "ffp_det_destroy": (None, [C.c_void_p]),
+    "ffp_det_infer_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _p(C.c_int32), C.c_int, C.c_int, C.c_float,
+                                      C.c_float, C.c_int, C.c_int, _p(C.c_float), _p(C.c_int32)]),
+    "ffp_det_infer_tiles_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _p(C.c_int32), C.c_int, C.c_int, C.c_float,
+                                          C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ffp_det_forward_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _p(C.c_int32), C.c_int, C.c_int, _p(C.c_float),
+                                      C.c_size_t, _p(C.c_int32)]),
+    "ffp_merge": (C.c_int, [C.c_int, _p(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _p(C.c_float), _p(C.c_int32),
+                            _p(C.c_int32)]),
+    "ffp_merge_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
+                                C.c_int, C.c_void_p]),
+    "ffp_sliced_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                     C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _p(C.c_float),
+                                     C.c_int, _p(C.c_int32)]),
+    "ffp_det_stage_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                    C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    _p(C.c_int32), _p(C.c_int32)]),
+    "ffp_det_last_ms": (C.c_int, [C.c_void_p, C.c_int, _p(C.c_float)]),
+    "ffp_det_last_conv_stats": (C.c_int, [C.c_void_p, _p(C.c_double), _p(C.c_float), _p(C.c_int32)]),
+    "ffp_det_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "ffp_det_profile_count": (C.c_int, [C.c_void_p, _p(C.c_int32)]),
+    "ffp_det_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, _p(C.c_double), _p(C.c_float), _p(C.c_int32)]),
+    "ffp_sr_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_void_p)]),
+    "ffp_sr_destroy": (None, [C.c_void_p]),
+    "ffp_sr_enhance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ffp_sr_enhance_batch": (C.c_int, [C.c_void_p, C.c_int, _p(C.c_void_p), _p(C.c_int32), _p(C.c_int32), C.c_int, C.c_int, C.c_int,
+                                       _p(C.c_void_p)]),
+    "ffp_sr_enhance_crops_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _p(C.c_int32), C.c_int, C.c_void_p, C.c_size_t,
+                                           _p(C.c_int64)]),
+    "ffp_sr_last_ms": (C.c_int, [C.c_void_p, _p(C.c_float)]),
+    "ffp_sr_last_conv_stats": (C.c_int, [C.c_void_p, _p(C.c_double), _p(C.c_float), _p(C.c_int32)]),
+    "ffp_sr_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "ffp_sr_profile_count": (C.c_int, [C.c_void_p, _p(C.c_int32)]),
+    "ffp_sr_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, _p(C.c_double), _p(C.c_float), _p(C.c_int32)]),
+    "ffp_op_conv2d": (C.c_int, [C.c_int, C.c_int, _p(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_float), _p(C.c_float), C.c_int,
+                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_float), C.c_float, _p(C.c_float)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+def lib() -> C.CDLL:
+    """Load libffp.so (in-tree). Raises if it has not been built — the product has no other implementation."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m ffp_amd.build` "
+                               "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(l, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise FfpError(rc, lib().ffp_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(lib().ffp_device_count(C.byref(n)))
+    return n.value
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(_p(C.c_float))
+
+
+def _ip(a: np.ndarray):
+    return a.ctypes.data_as(_p(C.c_int32))
+
+
+def slice_bboxes(H: int, W: int, slice_h: int, slice_w: int, overlap_h: float = 0.2, overlap_w: float = 0.2) -> np.ndarray:
+    n = C.c_int32(0)
+    _check(lib().ffp_slice_bboxes(H, W, slice_h, slice_w, overlap_h, overlap_w, None, 0, C.byref(n)))
+    out = np.zeros((n.value, 4), np.int32)
+    _check(lib().ffp_slice_bboxes(H, W, slice_h, slice_w, overlap_h, overlap_w, _ip(out), n.value, C.byref(n)))
+    return out
+
+
+def letterbox_geometry(h: int, w: int, imgsz: int) -> Tuple[int, int, int, int, int, int]:
+    out = np.zeros(6, np.int32)
+    _check(lib().ffp_letterbox_geometry(h, w, imgsz, _ip(out)))
+    return tuple(int(v) for v in out)
+
+
+def _weights_bytes(weights) -> bytes:
+    if isinstance(weights, (bytes, bytearray, memoryview)):
+        return bytes(weights)
+    if isinstance(weights, str):
+        with open(weights, "rb") as f:
+            return f.read()
+    return weights_io.pack(weights)
+
+
+def _as_frame(frame: np.ndarray) -> np.ndarray:
+    f = np.ascontiguousarray(frame)
+    if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] != 3:
+        raise ValueError(f"expected an HxWx3 uint8 array, got {f.dtype} {f.shape}")
+    return f
+
+
+class Detector:
+    """YOLO11{n,s}-pose on one GPU (ffp_det_*)."""
+
+    def __init__(self, weights, arch: str = "s", nc: int = 1, nkpt: int = 5, device: int = 0, precision: int = PREC_F32):
+        buf = _weights_bytes(weights)
+        self._h = C.c_void_p()
+        self.nc, self.nkpt, self.arch, self.device, self.precision = nc, nkpt, arch, device, precision
+        cbuf = C.create_string_buffer(buf, len(buf))
+        _check(lib().ffp_det_create(cbuf, len(buf), ord(arch), nc, nkpt, device, precision, C.byref(self._h)))
+
+    @property
+    def stride(self) -> int:
+        return 6 + 3 * self.nkpt
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().ffp_det_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def infer_tiles(self, frame: np.ndarray, tiles: Sequence[Sequence[int]], imgsz: int, conf: float, iou: float = 0.7,
+                    max_det: int = 300, chan_order: int = CHAN_AS_BGR, round_boxes: bool = False) -> List[np.ndarray]:
+        """-> per tile (n_i, 6+3*nkpt) float32 rows [x1,y1,x2,y2,score,cls,kpts] in tile-local pixels (not truncated)."""
+        f = _as_frame(frame)
+        t = np.ascontiguousarray(np.asarray(tiles, np.int32).reshape(-1, 4))
+        n = t.shape[0]
+        dets = np.zeros((n, max_det, self.stride), np.float32)
+        counts = np.zeros(n, np.int32)
+        _check(lib().ffp_det_infer_tiles(self._h, f.ctypes.data, f.shape[0], f.shape[1], chan_order, _ip(t), n, imgsz, conf, iou,
+                                         max_det, int(round_boxes), _fp(dets), _ip(counts)))
+        return [dets[i, :counts[i]].copy() for i in range(n)]
+
+    def forward_raw(self, frame: np.ndarray, tiles: Sequence[Sequence[int]], imgsz: int,
+                    chan_order: int = CHAN_AS_BGR) -> List[np.ndarray]:
+        """-> per tile the (4+nc+3*nkpt, A) inference-mode head output."""
+        f = _as_frame(frame)
+        t = np.ascontiguousarray(np.asarray(tiles, np.int32).reshape(-1, 4))
+        n = t.shape[0]
+        no = 4 + self.nc + 3 * self.nkpt
+        cap = 0
+        for x0, y0, x1, y1 in t:
+            sz = imgsz if imgsz > 0 else (max(t[0][2] - t[0][0], t[0][3] - t[0][1]) + 31) // 32 * 32
+            cap += no * (sz // 8) ** 2 * 2
+        out = np.zeros(cap, np.float32)
+        cnt = np.zeros(n, np.int32)
+        _check(lib().ffp_det_forward_raw(self._h, f.ctypes.data, f.shape[0], f.shape[1], chan_order, _ip(t), n, imgsz, _fp(out), cap, _ip(cnt)))
+        res, o = [], 0
+        for i in range(n):
+            a = int(cnt[i])
+            res.append(out[o:o + no * a].reshape(no, a).copy())
+            o += no * a
+        return res
+
+    def sliced_predict(self, frame: np.ndarray, slice_h: int, slice_w: int, overlap_h: float = 0.2, overlap_w: float = 0.2,
+                       perform_standard_pred: bool = True, imgsz: int = 1024, conf: float = 0.3, iou: float = 0.7, max_det: int = 300,
+                       pp_type: str = "GREEDYNMM", pp_metric: str = "IOS", pp_thr: float = 0.5, class_agnostic: bool = False,
+                       chan_order: int = CHAN_AS_BGR, round_boxes: bool = False, cap: int = 0) -> np.ndarray:
+        """Fused get_sliced_prediction -> (n, 6+3*nkpt) rows in frame coordinates (boxes int-valued)."""
+        f = _as_frame(frame)
+        H, W = f.shape[:2]
+        if cap <= 0:
+            cap = (len(slice_bboxes(H, W, slice_h, slice_w, overlap_h, overlap_w)) + 1) * max_det
+        out = np.zeros((cap, self.stride), np.float32)
+        n = C.c_int32(0)
+        _check(lib().ffp_sliced_predict(self._h, f.ctypes.data, H, W, chan_order, slice_h, slice_w, overlap_h, overlap_w,
+                                        int(perform_standard_pred), imgsz, conf, iou, max_det, int(round_boxes), PP_TYPES[pp_type],
+                                        METRICS[pp_metric], float(pp_thr), int(class_agnostic), _fp(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def last_ms(self) -> dict:
+        names = ["total", "preprocess", "network", "decode_nms", "merge"]
+        v = C.c_float(0)
+        out = {}
+        for i, k in enumerate(names):
+            _check(lib().ffp_det_last_ms(self._h, i, C.byref(v)))
+            out[k] = v.value
+        return out
+
+    def set_profile(self, on: bool):
+        _check(lib().ffp_det_set_profile(self._h, int(on)))
+
+    def profile(self) -> List[dict]:
+        return _profile(self._h, lib().ffp_det_profile_count, lib().ffp_det_profile_get)
+
+    def conv_stats(self) -> dict:
+        fl, ms, n = C.c_double(0), C.c_float(0), C.c_int32(0)
+        _check(lib().ffp_det_last_conv_stats(self._h, C.byref(fl), C.byref(ms), C.byref(n)))
+        return {"flops": fl.value, "ms": ms.value, "launches": n.value}
+
+
+def _profile(h, count_fn, get_fn) -> List[dict]:
+    n = C.c_int32(0)
+    _check(count_fn(h, C.byref(n)))
+    out = []
+    for i in range(n.value):
+        name = C.create_string_buffer(64)
+        fl, ms, ln = C.c_double(0), C.c_float(0), C.c_int32(0)
+        _check(get_fn(h, i, name, 64, C.byref(fl), C.byref(ms), C.byref(ln)))
+        out.append({"variant": name.value.decode(), "flops": fl.value, "ms": ms.value, "launches": ln.value})
+    return out
+
+
+def merge(rows: np.ndarray, pp_type: str = "GREEDYNMM", metric: str = "IOS", thr: float = 0.5, class_agnostic: bool = False,
+          device: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """SAHI post-process on (n, stride>=6) float32 rows -> (merged rows, source indices)."""
+    r = np.ascontiguousarray(rows, np.float32)
+    if r.ndim != 2 or r.shape[1] < 6:
+        raise ValueError("rows must be (n, >=6)")
+    n, stride = r.shape
+    out = np.zeros((max(n, 1), stride), np.float32)
+    src = np.zeros(max(n, 1), np.int32)
+    k = C.c_int32(0)
+    _check(lib().ffp_merge(device, _fp(r), n, stride, PP_TYPES[pp_type], METRICS[metric], float(thr), int(class_agnostic), _fp(out),
+                           _ip(src), C.byref(k)))
+    return out[:k.value].copy(), src[:k.value].copy()
+
+
+class Enhancer:
+    """Real-ESRGAN RRDBNet on one GPU (ffp_sr_*)."""
+
+    def __init__(self, weights, scale: int = 4, num_block: int = 23, device: int = 0, half: bool = True):
+        buf = _weights_bytes(weights)
+        self._h = C.c_void_p()
+        self.scale, self.num_block, self.device, self.half = scale, num_block, device, half
+        cbuf = C.create_string_buffer(buf, len(buf))
+        _check(lib().ffp_sr_create(cbuf, len(buf), scale, num_block, device, int(half), C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().ffp_sr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def enhance(self, img_bgr: np.ndarray, tile: int = 0, tile_pad: int = 10, pre_pad: int = 0) -> np.ndarray:
+        return self.enhance_batch([img_bgr], tile, tile_pad, pre_pad)[0]
+
+    def enhance_batch(self, imgs: Sequence[np.ndarray], tile: int = 0, tile_pad: int = 10, pre_pad: int = 0) -> List[np.ndarray]:
+        ins = [_as_frame(i) for i in imgs]
+        n = len(ins)
+        outs = [np.zeros((i.shape[0] * self.scale, i.shape[1] * self.scale, 3), np.uint8) for i in ins]
+        ip = (C.c_void_p * n)(*[i.ctypes.data for i in ins])
+        op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        hs = np.asarray([i.shape[0] for i in ins], np.int32)
+        ws = np.asarray([i.shape[1] for i in ins], np.int32)
+        _check(lib().ffp_sr_enhance_batch(self._h, n, ip, _ip(hs), _ip(ws), tile, tile_pad, pre_pad, op))
+        return outs
+
+    def last_ms(self) -> float:
+        v = C.c_float(0)
+        _check(lib().ffp_sr_last_ms(self._h, C.byref(v)))
+        return v.value
+
+    def set_profile(self, on: bool):
+        _check(lib().ffp_sr_set_profile(self._h, int(on)))
+
+    def profile(self) -> List[dict]:
+        return _profile(self._h, lib().ffp_sr_profile_count, lib().ffp_sr_profile_get)
+
+    def conv_stats(self) -> dict:
+        fl, ms, n = C.c_double(0), C.c_float(0), C.c_int32(0)
+        _check(lib().ffp_sr_last_conv_stats(self._h, C.byref(fl), C.byref(ms), C.byref(n)))
+        return {"flops": fl.value, "ms": ms.value, "launches": n.value}
+
+
+def op_conv2d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], stride: int = 1, groups: int = 1, act: int = 0, up: bool = False,
+              res: Optional[np.ndarray] = None, res_scale: float = 1.0, precision: int = PREC_F32, device: int = 0) -> np.ndarray:
+    """Single convolution through the HIP kernels. x: (n,h,w,cin) fp32 NHWC, w: (cout, cin/groups, k, k) -> (n,ho,wo,cout)."""
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    n, h, wd, cin = x.shape
+    cout, _, k, _ = w.shape
+    hi, wi = (h * 2, wd * 2) if up else (h, wd)
+    ho, wo = (hi + 2 * (k // 2) - k) // stride + 1, (wi + 2 * (k // 2) - k) // stride + 1
+    y = np.zeros((n, ho, wo, cout), np.float32)
+    bb = np.ascontiguousarray(b, np.float32) if b is not None else None
+    rr = np.ascontiguousarray(res, np.float32) if res is not None else None
+    _check(lib().ffp_op_conv2d(device, precision, _fp(x), n, h, wd, cin, _fp(w), _fp(bb) if bb is not None else None, cout, k, stride,
+                               groups, act, int(up), _fp(rr) if rr is not None else None, res_scale, _fp(y)))
+    return y

@@ -1,0 +1,70 @@
+"""Build libffp.so (hand-written HIP for gfx950 + the C-ABI) in-tree with hipcc. No torch, no cmake.
+
+    python -m <package>.build            or      from <package> import build; build.build()
+
+hipcc cross-compiles without a GPU; objects are cached under csrc/build/ by source mtime.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libffp.so")
+SOURCES = ["common.cpp", "weights.cpp", "engine.cpp", "conv_mfma.hip", "ops_misc.hip", "det_post.hip", "merge.hip",
+           "sr_ops.hip", "yolo11.cpp", "rrdb.cpp", "api.cpp"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
+         "-ffp-contract=off"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build libffp.so)")
+
+
+def _newest_header() -> float:
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    hs.append(os.path.join(HERE, "..", "include", "ffp.h"))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src: str, force: bool) -> str:
+    bdir = os.path.join(CSRC, "build")
+    os.makedirs(bdir, exist_ok=True)
+    obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
+    spath = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(spath), _newest_header()):
+        return obj
+    cmd = [_hipcc(), *FLAGS, "-c", spath, "-o", obj]
+    if src.endswith(".cpp"):
+        cmd.insert(1, "-x")
+        cmd.insert(2, "hip")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    if force or not os.path.exists(OUT) or any(os.path.getmtime(o) > os.path.getmtime(OUT) for o in objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {OUT} ({os.path.getsize(OUT) / 1e6:.1f} MB)")
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,438 @@
+// api.cpp — the C-ABI of libffp.so (include/ffp.h). Every entry point catches engine exceptions, stores a
+// thread-local message and returns an error code; nothing here computes on the CPU.
+#include <algorithm>
+#include <cmath>
+
+#include "sr_ops.hpp"
+#include "yolo11.hpp"
+
+namespace ffp {
+const std::string& last_error();
+}
+
+struct ffp_det { ffp::DetEngine eng; ffp_det(const void* w, size_t n, int a, int nc, int nk, int dev, int pr) : eng(w, n, a, nc, nk, dev, pr) {} };
+struct ffp_sr { ffp::SrEngine eng; ffp_sr(const void* w, size_t n, int s, int nb, int dev, int h) : eng(w, n, s, nb, dev, h) {} };
+
+using namespace ffp;
+
+#define FFP_API_BEGIN try {
+#define FFP_API_END                                                              \
+  return FFP_OK;                                                                 \
+  }                                                                              \
+  catch (const ffp::Error& e) { ffp::set_last_error(e.what()); return e.code; } \
+  catch (const std::bad_alloc&) { ffp::set_last_error("host out of memory"); return FFP_ERR_NOMEM; } \
+  catch (const std::exception& e) { ffp::set_last_error(e.what()); return FFP_ERR_STATE; }
+
+namespace {
+
+std::vector<int32_t> slice_bboxes(int H, int W, int sh, int sw, float oh, float ow) {
+  // sahi.slicing.get_slice_bboxes
+  FFP_CHECK(H > 0 && W > 0 && sh > 0 && sw > 0, FFP_ERR_ARG, "slice_bboxes: sizes must be positive");
+  FFP_CHECK(oh >= 0.f && oh < 1.f && ow >= 0.f && ow < 1.f, FFP_ERR_ARG, "slice_bboxes: overlap ratio must be in [0,1)");
+  std::vector<int32_t> out;
+  int y_max = 0, y_min = 0;
+  const int y_overlap = (int)((double)oh * sh), x_overlap = (int)((double)ow * sw);
+  while (y_max < H) {
+    int x_min = 0, x_max = 0;
+    y_max = y_min + sh;
+    while (x_max < W) {
+      x_max = x_min + sw;
+      if (y_max > H || x_max > W) {
+        const int xmax = std::min(W, x_max), ymax = std::min(H, y_max);
+        const int xmin = std::max(0, xmax - sw), ymin = std::max(0, ymax - sh);
+        out.insert(out.end(), {xmin, ymin, xmax, ymax});
+      } else {
+        out.insert(out.end(), {x_min, y_min, x_max, y_max});
+      }
+      x_min = x_max - x_overlap;
+    }
+    y_min = y_max - y_overlap;
+  }
+  return out;
+}
+
+void upload_frame(DetEngine& e, const uint8_t* frame, int H, int W) {
+  FFP_CHECK(frame && H > 0 && W > 0, FFP_ERR_ARG, "frame is null or empty");
+  FFP_HIP(hipSetDevice(e.device()));
+  const size_t nb = (size_t)H * W * 3;
+  e.scratch_frame.ensure(nb);
+  FFP_HIP(hipMemcpyAsync(e.scratch_frame.p, frame, nb, hipMemcpyHostToDevice, e.stream()));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ffp_last_error(void) { return ffp::last_error().c_str(); }
+int ffp_version(void) { return 100; }
+
+int ffp_device_count(int* out_n) {
+  FFP_API_BEGIN
+  FFP_CHECK(out_n, FFP_ERR_ARG, "null output");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  (void)hipGetLastError();
+  *out_n = n;
+  FFP_API_END
+}
+
+int ffp_slice_bboxes(int H, int W, int sh, int sw, float oh, float ow, int32_t* out_xyxy, int cap, int32_t* out_n) {
+  FFP_API_BEGIN
+  FFP_CHECK(out_n, FFP_ERR_ARG, "null output");
+  const std::vector<int32_t> b = slice_bboxes(H, W, sh, sw, oh, ow);
+  const int n = (int)b.size() / 4;
+  *out_n = n;
+  if (out_xyxy && cap > 0) std::memcpy(out_xyxy, b.data(), sizeof(int32_t) * 4 * (size_t)std::min(n, cap));
+  FFP_API_END
+}
+
+int ffp_letterbox_geometry(int h, int w, int imgsz, int32_t* out6) {
+  FFP_API_BEGIN
+  FFP_CHECK(out6 && h > 0 && w > 0 && imgsz > 0, FFP_ERR_ARG, "letterbox_geometry: bad arguments");
+  ffp::letterbox_geometry(h, w, imgsz, out6);
+  FFP_API_END
+}
+
+int ffp_det_create(const void* weights, size_t nbytes, int arch, int nc, int nkpt, int device, int precision, ffp_det** out) {
+  FFP_API_BEGIN
+  FFP_CHECK(out && weights, FFP_ERR_ARG, "null argument");
+  *out = new ffp_det(weights, nbytes, arch, nc, nkpt, device, precision);
+  FFP_API_END
+}
+
+void ffp_det_destroy(ffp_det* d) { delete d; }
+
+int ffp_det_infer_tiles(ffp_det* d, const uint8_t* frame, int H, int W, int chan_order, const int32_t* tiles, int n_tiles, int imgsz,
+                        float conf, float iou, int max_det, int round_boxes, float* out_dets, int32_t* out_counts) {
+  FFP_API_BEGIN
+  FFP_CHECK(d && out_dets && out_counts, FFP_ERR_ARG, "null argument");
+  DetEngine& e = d->eng;
+  upload_frame(e, frame, H, W);
+  FFP_CHECK(n_tiles > 0 && max_det >= 1 && max_det <= 1024, FFP_ERR_ARG, "n_tiles/max_det out of range");
+  const size_t nd = (size_t)n_tiles * max_det * e.det_stride();
+  e.scratch_dets.ensure(nd * 4);
+  e.scratch_counts.ensure(sizeof(int32_t) * n_tiles);
+  e.infer_tiles_dev(e.scratch_frame.as<uint8_t>(), H, W, chan_order, tiles, n_tiles, imgsz, conf, iou, max_det, round_boxes,
+                    e.scratch_dets.as<float>(), e.scratch_counts.as<int32_t>());
+  FFP_HIP(hipMemcpy(out_dets, e.scratch_dets.p, nd * 4, hipMemcpyDeviceToHost));
+  FFP_HIP(hipMemcpy(out_counts, e.scratch_counts.p, sizeof(int32_t) * n_tiles, hipMemcpyDeviceToHost));
+  FFP_API_END
+}
+
+int ffp_det_infer_tiles_dev(ffp_det* d, const uint8_t* d_frame, int H, int W, int chan_order, const int32_t* tiles, int n_tiles,
+                            int imgsz, float conf, float iou, int max_det, int round_boxes, float* d_out_dets, int32_t* d_out_counts) {
+  FFP_API_BEGIN
+  FFP_CHECK(d && d_frame && d_out_dets && d_out_counts, FFP_ERR_ARG, "null argument");
+  d->eng.infer_tiles_dev(d_frame, H, W, chan_order, tiles, n_tiles, imgsz, conf, iou, max_det, round_boxes, d_out_dets, d_out_counts);
+  FFP_API_END
+}
+
+int ffp_det_forward_raw(ffp_det* d, const uint8_t* frame, int H, int W, int chan_order, const int32_t* tiles, int n_tiles, int imgsz,
+                        float* out_raw, size_t out_cap, int32_t* out_anchor_counts) {
+  FFP_API_BEGIN
+  FFP_CHECK(d && out_raw && out_anchor_counts, FFP_ERR_ARG, "null argument");
+  DetEngine& e = d->eng;
+  upload_frame(e, frame, H, W);
+  e.forward_raw(e.scratch_frame.as<uint8_t>(), H, W, chan_order, tiles, n_tiles, imgsz, out_raw, out_cap, out_anchor_counts);
+  FFP_API_END
+}
+
+int ffp_merge(int device, const float* dets, int n, int stride, int type, int metric, double thr, int class_agnostic, float* out,
+              int32_t* out_src_index, int32_t* out_n) {
+  FFP_API_BEGIN
+  FFP_CHECK(out && out_n && n >= 0 && stride >= 6 && (dets || n == 0), FFP_ERR_ARG, "merge: bad arguments");
+  int ndev = 0;
+  FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "merge: no HIP device %d (no CPU path)", device);
+  FFP_HIP(hipSetDevice(device));
+  if (n == 0) { *out_n = 0; return FFP_OK; }
+  hipStream_t st;
+  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  try {
+    MergeWork w;
+    DevBuf rows(sizeof(float) * (size_t)n * stride), dn(sizeof(int)), dout(sizeof(float) * (size_t)n * stride), dsrc(sizeof(int) * (size_t)n),
+        doutn(sizeof(int));
+    FFP_HIP(hipMemcpyAsync(rows.p, dets, sizeof(float) * (size_t)n * stride, hipMemcpyHostToDevice, st));
+    FFP_HIP(hipMemcpyAsync(dn.p, &n, sizeof(int), hipMemcpyHostToDevice, st));
+    if (n > 1) run_merge(w, rows.as<float>(), dn.as<int>(), n, stride, type, metric, thr, class_agnostic, dout.as<float>(), dsrc.as<int>(),
+                         doutn.as<int>(), n, st);
+    else run_merge_passthrough(rows.as<float>(), dn.as<int>(), stride, dout.as<float>(), dsrc.as<int>(), doutn.as<int>(), n, st);
+    int k = 0;
+    FFP_HIP(hipMemcpyAsync(&k, doutn.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    FFP_HIP(hipStreamSynchronize(st));
+    FFP_HIP(hipMemcpy(out, dout.p, sizeof(float) * (size_t)k * stride, hipMemcpyDeviceToHost));
+    if (out_src_index) FFP_HIP(hipMemcpy(out_src_index, dsrc.p, sizeof(int) * (size_t)k, hipMemcpyDeviceToHost));
+    *out_n = k;
+  } catch (...) {
+    (void)hipStreamDestroy(st);
+    throw;
+  }
+  (void)hipStreamDestroy(st);
+  FFP_API_END
+}
+
+int ffp_merge_dev(ffp_det* d, const float* d_dets, const int32_t* d_counts, int n_slices, int max_det, int type, int metric, double thr,
+                  int class_agnostic, float* d_out, int cap, int32_t* d_out_n) {
+  FFP_API_BEGIN
+  FFP_CHECK(d && d_dets && d_counts && d_out && d_out_n && n_slices > 0 && cap > 0, FFP_ERR_ARG, "merge_dev: bad arguments");
+  d->eng.merge_dev(d_dets, d_counts, n_slices, max_det, type, metric, thr, class_agnostic, d_out, nullptr, cap, d_out_n);
+  FFP_API_END
+}
+
+// shared body of ffp_sliced_predict / ffp_det_stage_dev: detections of this rank's share of [slices..., full frame]
+static void stage(DetEngine& e, const uint8_t* d_frame, int H, int W, int chan_order, int slice_h, int slice_w, float oh, float ow,
+                  int perform_standard_pred, int imgsz, float conf, float iou, int max_det, int round_boxes, int rank, int world,
+                  float* d_dets, int32_t* d_counts, int* n_local, int* n_total) {
+  FFP_CHECK(world >= 1 && rank >= 0 && rank < world, FFP_ERR_ARG, "rank %d of %d", rank, world);
+  std::vector<int32_t> items = slice_bboxes(H, W, slice_h, slice_w, oh, ow);
+  const int n_slices = (int)items.size() / 4;
+  if (n_slices > 1 && perform_standard_pred) items.insert(items.end(), {0, 0, W, H});   // docs sahi/predict.py:301-314
+  const int total = (int)items.size() / 4;
+  const int per = (total + world - 1) / world;
+  const int lo = std::min(rank * per, total), hi = std::min(lo + per, total);
+  *n_total = total;
+  *n_local = hi - lo;
+  if (hi > lo) {
+    e.infer_tiles_dev(d_frame, H, W, chan_order, items.data() + 4 * lo, hi - lo, imgsz, conf, iou, max_det, round_boxes, d_dets, d_counts);
+    e.truncate_shift_dev(d_dets, d_counts, hi - lo, max_det, H, W);
+  }
+}
+
+int ffp_sliced_predict(ffp_det* d, const uint8_t* frame, int H, int W, int chan_order, int slice_h, int slice_w, float oh, float ow,
+                       int perform_standard_pred, int imgsz, float conf, float iou, int max_det, int round_boxes, int pp_type,
+                       int pp_metric, double pp_thr, int class_agnostic, float* out, int cap, int32_t* out_n) {
+  FFP_API_BEGIN
+  FFP_CHECK(d && out && out_n && cap > 0, FFP_ERR_ARG, "null argument");
+  DetEngine& e = d->eng;
+  upload_frame(e, frame, H, W);
+  const std::vector<int32_t> sl = slice_bboxes(H, W, slice_h, slice_w, oh, ow);
+  const int total = (int)sl.size() / 4 + ((sl.size() / 4 > 1 && perform_standard_pred) ? 1 : 0);
+  const int stride = e.det_stride();
+  e.scratch_dets.ensure(sizeof(float) * (size_t)total * max_det * stride);
+  e.scratch_counts.ensure(sizeof(int32_t) * total);
+  int nl = 0, nt = 0;
+  stage(e, e.scratch_frame.as<uint8_t>(), H, W, chan_order, slice_h, slice_w, oh, ow, perform_standard_pred, imgsz, conf, iou, max_det,
+        round_boxes, 0, 1, e.scratch_dets.as<float>(), e.scratch_counts.as<int32_t>(), &nl, &nt);
+  e.scratch_out.ensure(sizeof(float) * (size_t)cap * stride);
+  e.scratch_outn.ensure(sizeof(int));
+  e.merge_dev(e.scratch_dets.as<float>(), e.scratch_counts.as<int32_t>(), total, max_det, pp_type, pp_metric, pp_thr, class_agnostic,
+              e.scratch_out.as<float>(), nullptr, cap, e.scratch_outn.as<int32_t>());
+  int k = 0;
+  FFP_HIP(hipMemcpy(&k, e.scratch_outn.p, sizeof(int), hipMemcpyDeviceToHost));
+  FFP_HIP(hipMemcpy(out, e.scratch_out.p, sizeof(float) * (size_t)k * stride, hipMemcpyDeviceToHost));
+  *out_n = k;
+  FFP_API_END
+}
+
+int ffp_det_stage_dev(ffp_det* d, const uint8_t* d_frame, int H, int W, int chan_order, int slice_h, int slice_w, float oh, float ow,
+                      int perform_standard_pred, int imgsz, float conf, float iou, int max_det, int round_boxes, int rank, int world,
+                      float* d_local_dets, int32_t* d_local_counts, int32_t* out_n_local, int32_t* out_n_total) {
+  FFP_API_BEGIN
+  FFP_CHECK(d && d_frame && d_local_dets && d_local_counts && out_n_local && out_n_total, FFP_ERR_ARG, "null argument");
+  int nl = 0, nt = 0;
+  stage(d->eng, d_frame, H, W, chan_order, slice_h, slice_w, oh, ow, perform_standard_pred, imgsz, conf, iou, max_det, round_boxes, rank,
+        world, d_local_dets, d_local_counts, &nl, &nt);
+  *out_n_local = nl;
+  *out_n_total = nt;
+  FFP_API_END
+}
+
+int ffp_det_last_ms(ffp_det* d, int stage_id, float* out_ms) {
+  FFP_API_BEGIN
+  FFP_CHECK(d && out_ms && stage_id >= 0 && stage_id < 5, FFP_ERR_ARG, "bad argument");
+  *out_ms = d->eng.last_ms[stage_id];
+  FFP_API_END
+}
+
+int ffp_det_last_conv_stats(ffp_det* d, double* out_flops, float* out_ms, int32_t* out_launches) {
+  FFP_API_BEGIN
+  FFP_CHECK(d, FFP_ERR_ARG, "null handle");
+  if (out_flops) *out_flops = d->eng.last_conv_flops;
+  if (out_launches) *out_launches = d->eng.last_conv_launches;
+  if (out_ms) { double ms = 0; for (auto& kv : d->eng.prof.table) ms += kv.second.ms; *out_ms = (float)ms; }
+  FFP_API_END
+}
+
+static int profile_get(ConvProfile& p, int i, char* name, int cap, double* flops, float* ms, int32_t* launches) {
+  if (i < 0 || i >= (int)p.table.size()) return FFP_ERR_ARG;
+  auto it = p.table.begin();
+  std::advance(it, i);
+  if (name && cap > 0) { std::snprintf(name, cap, "%s", it->second.variant.c_str()); }
+  if (flops) *flops = it->second.flops;
+  if (ms) *ms = (float)it->second.ms;
+  if (launches) *launches = it->second.launches;
+  return FFP_OK;
+}
+
+int ffp_det_set_profile(ffp_det* d, int enable) { if (!d) return FFP_ERR_ARG; d->eng.prof.enabled = enable != 0; return FFP_OK; }
+int ffp_det_profile_count(ffp_det* d, int32_t* n) { if (!d || !n) return FFP_ERR_ARG; *n = (int)d->eng.prof.table.size(); return FFP_OK; }
+int ffp_det_profile_get(ffp_det* d, int i, char* name, int cap, double* flops, float* ms, int32_t* launches) {
+  if (!d) return FFP_ERR_ARG;
+  return profile_get(d->eng.prof, i, name, cap, flops, ms, launches);
+}
+
+// ---- super-resolution ---------------------------------------------------------------------------------------------------
+int ffp_sr_create(const void* weights, size_t nbytes, int scale, int num_block, int device, int half, ffp_sr** out) {
+  FFP_API_BEGIN
+  FFP_CHECK(out && weights, FFP_ERR_ARG, "null argument");
+  *out = new ffp_sr(weights, nbytes, scale, num_block, device, half);
+  FFP_API_END
+}
+
+void ffp_sr_destroy(ffp_sr* s) { delete s; }
+
+int ffp_sr_enhance_batch(ffp_sr* s, int n, const uint8_t* const* imgs, const int32_t* hs, const int32_t* ws, int tile, int tile_pad,
+                         int pre_pad, uint8_t* const* outs) {
+  FFP_API_BEGIN
+  FFP_CHECK(s && n > 0 && imgs && hs && ws && outs, FFP_ERR_ARG, "bad argument");
+  SrEngine& e = s->eng;
+  FFP_HIP(hipSetDevice(e.device()));
+  const int sc = e.scale();
+  std::vector<SrImage> v(n);
+  size_t in_tot = 0, out_tot = 0;
+  for (int i = 0; i < n; ++i) {
+    FFP_CHECK(imgs[i] && outs[i] && hs[i] > 0 && ws[i] > 0, FFP_ERR_ARG, "image %d is null or empty", i);
+    v[i].in_off = (long long)in_tot; v[i].in_stride = ws[i] * 3; v[i].h = hs[i]; v[i].w = ws[i];
+    v[i].out_off = (long long)out_tot; v[i].out_stride = ws[i] * sc * 3;
+    in_tot += ((size_t)hs[i] * ws[i] * 3 + 15) / 16 * 16;
+    out_tot += ((size_t)hs[i] * sc * ws[i] * sc * 3 + 15) / 16 * 16;
+  }
+  e.scratch_in.ensure(in_tot);
+  e.scratch_out.ensure(out_tot);
+  for (int i = 0; i < n; ++i)
+    FFP_HIP(hipMemcpyAsync(e.scratch_in.as<uint8_t>() + v[i].in_off, imgs[i], (size_t)hs[i] * ws[i] * 3, hipMemcpyHostToDevice, e.stream()));
+  e.enhance_dev(e.scratch_in.as<uint8_t>(), e.scratch_out.as<uint8_t>(), v, tile, tile_pad, pre_pad);
+  for (int i = 0; i < n; ++i)
+    FFP_HIP(hipMemcpy(outs[i], e.scratch_out.as<uint8_t>() + v[i].out_off, (size_t)hs[i] * sc * ws[i] * sc * 3, hipMemcpyDeviceToHost));
+  FFP_API_END
+}
+
+int ffp_sr_enhance(ffp_sr* s, const uint8_t* bgr, int h, int w, int tile, int tile_pad, int pre_pad, uint8_t* out_bgr) {
+  const uint8_t* ins[1] = {bgr};
+  uint8_t* outs[1] = {out_bgr};
+  const int32_t hs[1] = {h}, ws[1] = {w};
+  return ffp_sr_enhance_batch(s, 1, ins, hs, ws, tile, tile_pad, pre_pad, outs);
+}
+
+int ffp_sr_enhance_crops_dev(ffp_sr* s, const uint8_t* d_frame, int H, int W, const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap,
+                             int64_t* out_offsets) {
+  FFP_API_BEGIN
+  FFP_CHECK(s && d_frame && boxes && n > 0 && d_out && out_offsets, FFP_ERR_ARG, "bad argument");
+  SrEngine& e = s->eng;
+  FFP_HIP(hipSetDevice(e.device()));
+  const int sc = e.scale();
+  std::vector<SrImage> v(n);
+  std::vector<int4> hb(n);
+  std::vector<long long> offs(n);
+  size_t in_tot = 0, out_tot = 0;
+  for (int i = 0; i < n; ++i) {
+    // utils/visualization.py:204-213: int box, clamp to the frame, skip empty
+    int x1 = std::max(0, boxes[4 * i]), y1 = std::max(0, boxes[4 * i + 1]);
+    int x2 = std::min(W, boxes[4 * i + 2]), y2 = std::min(H, boxes[4 * i + 3]);
+    FFP_CHECK(x2 > x1 && y2 > y1, FFP_ERR_ARG, "crop %d is empty after clamping", i);
+    const int w = x2 - x1, h = y2 - y1;
+    hb[i] = make_int4(x1, y1, w, h);
+    offs[i] = (long long)in_tot;
+    v[i].in_off = (long long)in_tot; v[i].in_stride = w * 3; v[i].h = h; v[i].w = w;
+    v[i].out_off = (long long)out_tot; v[i].out_stride = w * sc * 3;
+    out_offsets[i] = (int64_t)out_tot;
+    in_tot += ((size_t)h * w * 3 + 15) / 16 * 16;
+    out_tot += ((size_t)h * sc * w * sc * 3 + 15) / 16 * 16;
+  }
+  out_offsets[n] = (int64_t)out_tot;
+  FFP_CHECK(out_tot <= out_cap, FFP_ERR_ARG, "output needs %zu bytes, capacity %zu", out_tot, out_cap);
+  e.scratch_in.ensure(in_tot);
+  e.scratch_boxes.ensure(sizeof(int4) * n);
+  e.scratch_offs.ensure(sizeof(long long) * n);
+  FFP_HIP(hipMemcpyAsync(e.scratch_boxes.p, hb.data(), sizeof(int4) * n, hipMemcpyHostToDevice, e.stream()));
+  FFP_HIP(hipMemcpyAsync(e.scratch_offs.p, offs.data(), sizeof(long long) * n, hipMemcpyHostToDevice, e.stream()));
+  launch_crop_gather(d_frame, W, e.scratch_boxes.as<int4>(), e.scratch_offs.as<long long>(), n, e.scratch_in.as<uint8_t>(), e.stream());
+  FFP_HIP(hipStreamSynchronize(e.stream()));
+  e.enhance_dev(e.scratch_in.as<uint8_t>(), d_out, v, 0, 10, 0);
+  FFP_API_END
+}
+
+int ffp_sr_last_ms(ffp_sr* s, float* out_ms) { if (!s || !out_ms) return FFP_ERR_ARG; *out_ms = s->eng.last_ms; return FFP_OK; }
+int ffp_sr_last_conv_stats(ffp_sr* s, double* out_flops, float* out_ms, int32_t* out_launches) {
+  if (!s) return FFP_ERR_ARG;
+  if (out_flops) *out_flops = s->eng.last_conv_flops;
+  if (out_launches) *out_launches = s->eng.last_conv_launches;
+  if (out_ms) { double ms = 0; for (auto& kv : s->eng.prof.table) ms += kv.second.ms; *out_ms = (float)ms; }
+  return FFP_OK;
+}
+int ffp_sr_set_profile(ffp_sr* s, int enable) { if (!s) return FFP_ERR_ARG; s->eng.prof.enabled = enable != 0; return FFP_OK; }
+int ffp_sr_profile_count(ffp_sr* s, int32_t* n) { if (!s || !n) return FFP_ERR_ARG; *n = (int)s->eng.prof.table.size(); return FFP_OK; }
+int ffp_sr_profile_get(ffp_sr* s, int i, char* name, int cap, double* flops, float* ms, int32_t* launches) {
+  if (!s) return FFP_ERR_ARG;
+  return profile_get(s->eng.prof, i, name, cap, flops, ms, launches);
+}
+
+// ---- single operator (parity tests) ------------------------------------------------------------------------------------------
+int ffp_op_conv2d(int device, int precision, const float* x, int n, int h, int w, int cin, const float* wt, const float* bias, int cout,
+                  int k, int stride, int groups, int act, int up, const float* res, float res_scale, float* y) {
+  FFP_API_BEGIN
+  FFP_CHECK(x && wt && y && n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, FFP_ERR_ARG, "conv2d: bad arguments");
+  FFP_CHECK((k == 1 || k == 3) && (stride == 1 || stride == 2), FFP_ERR_ARG, "conv2d: k in {1,3}, stride in {1,2}");
+  int ndev = 0;
+  FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "conv2d: no HIP device %d (no CPU path)", device);
+  FFP_HIP(hipSetDevice(device));
+  conv_kernels_init();
+  const DType T = precision == FFP_PREC_F16 ? F16 : F32;
+  hipStream_t st;
+  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  try {
+    PackedConv pc;
+    pack_conv(pc, "op", wt, bias, cout, cin, k, groups, T, st);
+    const int hi = up ? h * 2 : h, wi = up ? w * 2 : w;
+    const int ho = (hi + 2 * (k / 2) - k) / stride + 1, wo = (wi + 2 * (k / 2) - k) / stride + 1;
+    Level lin, lout;
+    lin.build(std::vector<int>(n, h), std::vector<int>(n, w), st);
+    lout.build(std::vector<int>(n, ho), std::vector<int>(n, wo), st);
+    const int cin_s = pc.depthwise() ? cin : pc.cin;        // stored (padded) input channels
+    const size_t npx_in = (size_t)lin.total_px, npx_out = (size_t)lout.total_px;
+    auto to_dev = [&](const float* src, size_t px, int c, int c_store) {
+      DevBuf b(px * c_store * dsize(T) + 256);
+      if (T == F32) {
+        std::vector<float> t(px * c_store, 0.f);
+        for (size_t p = 0; p < px; ++p) std::memcpy(&t[p * c_store], src + p * c, sizeof(float) * c);
+        FFP_HIP(hipMemcpy(b.p, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+      } else {
+        std::vector<_Float16> t(px * c_store, (_Float16)0.f);
+        for (size_t p = 0; p < px; ++p) for (int q = 0; q < c; ++q) t[p * c_store + q] = (_Float16)src[p * c + q];
+        FFP_HIP(hipMemcpy(b.p, t.data(), t.size() * 2, hipMemcpyHostToDevice));
+      }
+      return b;
+    };
+    DevBuf din = to_dev(x, npx_in, cin, cin_s);
+    DevBuf dres;
+    if (res) dres = to_dev(res, npx_out, cout, cout);
+    DevBuf dout(npx_out * cout * dsize(T) + 256);
+    TView vin{din.p, T, cin_s, 0, cin_s, &lin}, vout{dout.p, T, cout, 0, cout, &lout}, vres{dres.p, T, cout, 0, cout, &lout};
+    if (pc.depthwise()) {
+      FFP_CHECK(k == 3 && stride == 1 && !up, FFP_ERR_ARG, "conv2d: depthwise is 3x3 stride 1");
+      DwConvOp o;
+      o.pc = &pc; o.in = vin; o.out = vout; o.out.lvl = &lin; o.act = act;
+      if (res) { o.has_res = true; o.res = vres; o.res.lvl = &lin; FFP_CHECK(res_scale == 1.f, FFP_ERR_ARG, "conv2d: depthwise residual has no scale"); }
+      launch_dwconv(o, st);
+    } else {
+      ConvOp o;
+      o.pc = &pc; o.in = vin; o.out = vout; o.stride = stride; o.act = act; o.up = up;
+      if (res) { o.has_res1 = true; o.res1 = vres; o.s1 = res_scale; }
+      launch_conv(o, st);
+    }
+    FFP_HIP(hipStreamSynchronize(st));
+    if (T == F32) {
+      FFP_HIP(hipMemcpy(y, dout.p, npx_out * cout * 4, hipMemcpyDeviceToHost));
+    } else {
+      std::vector<_Float16> t(npx_out * cout);
+      FFP_HIP(hipMemcpy(t.data(), dout.p, t.size() * 2, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < t.size(); ++i) y[i] = (float)t[i];
+    }
+  } catch (...) {
+    (void)hipStreamDestroy(st);
+    throw;
+  }
+  (void)hipStreamDestroy(st);
+  FFP_API_END
+}
+
+}  // extern "C"

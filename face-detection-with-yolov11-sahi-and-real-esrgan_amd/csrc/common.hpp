@@ -1,0 +1,96 @@
+// common.hpp — error plumbing, device buffers and the tensor/level vocabulary shared by every translation unit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ffp.h"
+
+namespace ffp {
+
+// ---- errors ---------------------------------------------------------------------------------------------
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+void set_last_error(const std::string& m);
+[[noreturn]] void fail(int code, const char* fmt, ...);
+
+#define FFP_HIP(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) ::ffp::fail(FFP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+#define FFP_CHECK(cond, code, ...)            \
+  do {                                        \
+    if (!(cond)) ::ffp::fail(code, __VA_ARGS__); \
+  } while (0)
+
+// ---- element types --------------------------------------------------------------------------------------
+enum DType : int { F32 = 0, F16 = 1 };
+inline int dsize(DType t) { return t == F32 ? 4 : 2; }
+
+// ---- device memory ---------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  explicit DevBuf(size_t bytes) { alloc(bytes); }
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void alloc(size_t bytes) {
+    release();
+    if (bytes == 0) bytes = 16;
+    FFP_HIP(hipMalloc(&p, bytes));
+    n = bytes;
+  }
+  void ensure(size_t bytes) { if (bytes > n) alloc(bytes); }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ---- a batch of images at one resolution ("level") -------------------------------------------------------
+// Activations are NHWC; the images of a batch may differ in size (ragged) and are stored back to back, so a level is
+// a table {pixel offset, h, w} per image. 1x1 convolutions see one flat pixel array; 3x3 ones walk a tile table.
+struct Level {
+  int n = 0;
+  std::vector<int> h, w;
+  std::vector<int64_t> off;      // pixel offset of image i
+  int64_t total_px = 0;
+  DevBuf d_tab;                   // int4 {off, h, w, 0} per image
+  // tile tables keyed by tile height (tile width is always 16): int4 {img, y0, x0, 0}
+  std::map<int, std::pair<DevBuf, int>> tiles;
+
+  void build(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st);
+  const int4* tile_table(int th, int* n_tiles, hipStream_t st);
+};
+
+// A view of `C` channels starting at `coff` inside pixel records of `cs` elements.
+struct TView {
+  void* ptr = nullptr;
+  DType dt = F32;
+  int cs = 0, coff = 0, C = 0;
+  Level* lvl = nullptr;
+  TView slice(int c0, int c) const { TView v = *this; v.coff += c0; v.C = c; return v; }
+};
+
+// ---- activation codes ------------------------------------------------------------------------------------
+enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_LRELU = 2 };
+
+}  // namespace ffp

@@ -1,0 +1,375 @@
+// conv_mfma.hip — dense convolution as an im2col-free implicit GEMM on the gfx950 matrix cores.
+//
+// One launch convolves a whole ragged batch (images of different sizes stored back to back, NHWC).
+//   D[out channel][pixel] += W[out channel][tap, c] * X[tap-shifted pixel][c]
+// The MFMA A operand is a pre-packed weight fragment (32 out channels x one k-group, weights.cpp), the B operand a
+// pixel fragment (32 pixels = 2 tile rows x 16 columns, k contiguous) read from an LDS-staged halo tile, so the
+// accumulator holds, per lane, ONE pixel and 16 out channels in groups of 4 consecutive channels -> 16-byte
+// (fp32) / 8-byte (fp16) epilogue stores.
+//   fp16: v_mfma_f32_32x32x16_f16, k-group = 16 channels      (FFP_PREC_F16)
+//   fp32: 4 x v_mfma_f32_32x32x2_f32 per 8-channel k-group      (FFP_PREC_F32, exact-f32 fmaf chain)
+// Workgroup = 256 threads = 4 waves laid out WM x WN; a wave owns MI pixel fragments x NIW 32-channel tiles.
+// blockIdx is remapped so that the n-blocks of one pixel tile and neighbouring tiles share an XCD (L2 reuse of the
+// input tile); the mapping only affects speed.
+#include "ops.hpp"
+
+namespace ffp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvArgs {
+  const void* in;
+  const void* wpk;
+  const float* bias;
+  void* out;
+  const void* res1;
+  const void* res2;
+  const int4* in_tab;
+  const int4* out_tab;
+  const int4* tiles;
+  long long total_px;   // KS == 1: flat pixel count
+  int in_cs, in_coff, cin, cin_pad;
+  int out_cs, out_coff, cout;
+  int r1_cs, r1_coff, r2_cs, r2_coff;
+  float s1, s2;
+  int act, out_f32, up, n_nblk, ncg, ntiles32, vec_ok;
+};
+
+template <typename T> struct MM;
+template <> struct MM<float> {
+  static constexpr int KG = 8;
+  static __device__ __forceinline__ void mma(f32x16& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+template <> struct MM<_Float16> {
+  static constexpr int KG = 16;
+  static __device__ __forceinline__ void mma(f32x16& acc, const uint4& a, const uint4& b) {
+    union { uint4 u; f16x8 h; } ua, ub;
+    ua.u = a; ub.u = b;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ua.h, ub.h, acc, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  // blocks b and b+8 share an XCD (observed round-robin dispatch): give each XCD a contiguous run of logical ids.
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == ACT_SILU) return v / (1.0f + expf(-v));
+  if (act == ACT_LRELU) return v >= 0.f ? v : v * 0.2f;
+  return v;
+}
+
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&r)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&r)[4]) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+}
+template <> __device__ __forceinline__ void load4<_Float16>(const _Float16* p, float (&r)[4]) {
+  union { uint2 u; _Float16 h[4]; } v;
+  v.u = *reinterpret_cast<const uint2*>(p);
+  r[0] = (float)v.h[0]; r[1] = (float)v.h[1]; r[2] = (float)v.h[2]; r[3] = (float)v.h[3];
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float (&r)[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&r)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+}
+template <> __device__ __forceinline__ void store4<_Float16>(_Float16* p, const float (&r)[4]) {
+  union { uint2 u; _Float16 h[4]; } v;
+  v.h[0] = (_Float16)r[0]; v.h[1] = (_Float16)r[1]; v.h[2] = (_Float16)r[2]; v.h[3] = (_Float16)r[3];
+  *reinterpret_cast<uint2*>(p) = v.u;
+}
+
+template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int KC>
+__global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int ES = sizeof(T);
+  constexpr int KG = MM<T>::KG;
+  constexpr int FR = WM * MI;                       // pixel fragments per workgroup (32 px each)
+  constexpr int TH = FR * 2;                        // output tile rows (16 columns)
+  constexpr int HH = KS == 1 ? 1 : (TH - 1) * STRIDE + KS;
+  constexpr int HW = KS == 1 ? FR * 32 : 15 * STRIDE + KS;
+  constexpr int NPIX = HH * HW;                     // staged input pixels
+  constexpr int PS = KC * ES + 16;                  // LDS bytes per pixel record (+1 b128 pad against bank conflicts)
+  constexpr int VPP = KC * ES / 16;                 // 16-byte vectors per pixel per chunk
+  constexpr int EPV = 16 / ES;                      // elements per vector
+  constexpr int TAPS = KS * KS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int p = lane & 31, hh = lane >> 5;
+
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int nblk = L % a.n_nblk, tile = L / a.n_nblk;
+
+  int oy0 = 0, ox0 = 0, Ho = 1, Wo = 0, Hi = 0, Wi = 0;
+  long long in_base, out_base;
+  if (KS == 3) {
+    const int4 t = a.tiles[tile];
+    const int4 it = a.in_tab[t.x], ot = a.out_tab[t.x];
+    oy0 = t.y; ox0 = t.z;
+    in_base = it.x; Hi = it.y; Wi = it.z;
+    out_base = ot.x; Ho = ot.y; Wo = ot.z;
+  } else {
+    in_base = out_base = (long long)tile * NPIX;
+  }
+  const int iy0 = oy0 * STRIDE - (KS / 2), ix0 = ox0 * STRIDE - (KS / 2);
+  const int Hv = Hi << a.up, Wv = Wi << a.up;      // input size seen through the optional nearest x2
+
+  int boff[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int f = wm * MI + mi;
+    const int pix = KS == 1 ? f * 32 + p : ((2 * f + (p >> 4)) * STRIDE) * HW + (p & 15) * STRIDE;
+    boff[mi] = pix * PS + hh * 16;
+  }
+  const unsigned char* wlane = reinterpret_cast<const unsigned char*>(a.wpk) + lane * 16;
+  const int ntile0 = (nblk * WN + wn) * NIW;
+  size_t wrow[NIW];
+#pragma unroll
+  for (int ni = 0; ni < NIW; ++ni) {
+    const int nt = min(ntile0 + ni, a.ntiles32 - 1);
+    wrow[ni] = (size_t)nt * TAPS * a.ncg * 1024;
+  }
+
+  f32x16 acc[NIW][MI];
+#pragma unroll
+  for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+  const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in);
+
+  for (int c0 = 0; c0 < a.cin; c0 += KC) {
+    if (c0) __syncthreads();
+    // ---- stage the input (halo) tile chunk: global -> registers -> LDS, zero fill outside the image / past Cin
+#pragma unroll 4
+    for (int i = tid; i < NPIX * VPP; i += 256) {
+      const int hp = i / VPP, v = i % VPP;
+      const int c = c0 + v * EPV;
+      uint4 val = make_uint4(0u, 0u, 0u, 0u);
+      if (c < a.cin) {
+        long long gp;
+        bool ok;
+        if (KS == 1) {
+          gp = in_base + hp;
+          ok = gp < a.total_px;
+        } else {
+          const int hy = hp / HW, hx = hp - hy * HW;
+          const int iy = iy0 + hy, ix = ix0 + hx;
+          ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+          gp = in_base + (long long)(iy >> a.up) * Wi + (ix >> a.up);
+        }
+        if (ok) val = *reinterpret_cast<const uint4*>(inb + ((size_t)gp * a.in_cs + a.in_coff + c) * ES);
+      }
+      *reinterpret_cast<uint4*>(smem + hp * PS + v * 16) = val;
+    }
+    __syncthreads();
+
+    const int kmax = min(KC, a.cin_pad - c0) / KG;
+    const int cg0 = c0 / KG;
+    for (int ks = 0; ks < kmax; ++ks) {
+      const unsigned char* wk = wlane + (size_t)(cg0 + ks) * 1024;
+      const unsigned char* sk = smem + ks * (KG * ES);
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int ky = tap / KS, kx = tap % KS;
+        uint4 bf[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          bf[mi] = *reinterpret_cast<const uint4*>(sk + boff[mi] + (ky * HW + kx) * PS);
+#pragma unroll
+        for (int ni = 0; ni < NIW; ++ni) {
+          const uint4 af = *reinterpret_cast<const uint4*>(wk + wrow[ni] + (size_t)tap * a.ncg * 1024);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) MM<T>::mma(acc[ni][mi], af, bf[mi]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias, activation, residual(s), store. Lane = one pixel; regs 4g..4g+3 = channels 8g+4hh..+3.
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int f = wm * MI + mi;
+    long long gp;
+    bool ok;
+    if (KS == 1) {
+      gp = out_base + f * 32 + p;
+      ok = gp < a.total_px;
+    } else {
+      const int oy = oy0 + 2 * f + (p >> 4), ox = ox0 + (p & 15);
+      ok = oy < Ho && ox < Wo;
+      gp = out_base + (long long)oy * Wo + ox;
+    }
+    if (!ok) continue;
+#pragma unroll
+    for (int ni = 0; ni < NIW; ++ni) {
+      const int nt = ntile0 + ni;
+      if (nt >= a.ntiles32) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ch = nt * 32 + 8 * g + 4 * hh;
+        if (ch >= a.cout) continue;
+        float v[4];
+        const float4 bv = *reinterpret_cast<const float4*>(a.bias + ch);
+        v[0] = acc[ni][mi][4 * g + 0] + bv.x;
+        v[1] = acc[ni][mi][4 * g + 1] + bv.y;
+        v[2] = acc[ni][mi][4 * g + 2] + bv.z;
+        v[3] = acc[ni][mi][4 * g + 3] + bv.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], a.act);
+        const bool vec = a.vec_ok && ch + 3 < a.cout;
+        if (a.res1) {
+          const T* rp = reinterpret_cast<const T*>(a.res1) + (size_t)gp * a.r1_cs + a.r1_coff + ch;
+          float r[4] = {0.f, 0.f, 0.f, 0.f};
+          if (vec) load4<T>(rp, r);
+          else for (int j = 0; j < 4; ++j) if (ch + j < a.cout) r[j] = (float)rp[j];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = v[j] * a.s1 + r[j];
+        }
+        if (a.res2) {
+          const T* rp = reinterpret_cast<const T*>(a.res2) + (size_t)gp * a.r2_cs + a.r2_coff + ch;
+          float r[4] = {0.f, 0.f, 0.f, 0.f};
+          if (vec) load4<T>(rp, r);
+          else for (int j = 0; j < 4; ++j) if (ch + j < a.cout) r[j] = (float)rp[j];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = v[j] * a.s2 + r[j];
+        }
+        const size_t oidx = (size_t)gp * a.out_cs + a.out_coff + ch;
+        if (a.out_f32) {
+          float* op = reinterpret_cast<float*>(a.out) + oidx;
+          if (vec) store4<float>(op, v);
+          else for (int j = 0; j < 4; ++j) if (ch + j < a.cout) op[j] = v[j];
+        } else {
+          T* op = reinterpret_cast<T*>(a.out) + oidx;
+          if (vec) store4<T>(op, v);
+          else for (int j = 0; j < 4; ++j) if (ch + j < a.cout) op[j] = (T)v[j];
+        }
+      }
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int KC> struct Cfg {
+  static constexpr int ES = sizeof(T);
+  static constexpr int FR = WM * MI;
+  static constexpr int TH = FR * 2;
+  static constexpr int HH = KS == 1 ? 1 : (TH - 1) * STRIDE + KS;
+  static constexpr int HW = KS == 1 ? FR * 32 : 15 * STRIDE + KS;
+  static constexpr int LDS = HH * HW * (KC * ES + 16);
+  static constexpr int BLOCK_PX = FR * 32;
+  static constexpr int BLOCK_N = WN * NIW * 32;
+  static auto kernel() { return &conv_mfma_kernel<T, KS, STRIDE, WM, WN, MI, NIW, KC>; }
+  static void init() {
+    FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel()), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+  }
+  static void launch(ConvArgs& a, Level* out_lvl, hipStream_t st) {
+    int n_tiles;
+    if (KS == 1) {
+      n_tiles = (int)((a.total_px + BLOCK_PX - 1) / BLOCK_PX);
+    } else {
+      a.tiles = out_lvl->tile_table(TH, &n_tiles, st);
+    }
+    a.n_nblk = (a.ntiles32 * 32 + BLOCK_N - 1) / BLOCK_N;
+    const int grid = n_tiles * a.n_nblk;
+    if (grid == 0) return;
+    hipLaunchKernelGGL(kernel(), dim3(grid), dim3(256), LDS, st, a);
+  }
+};
+
+// chunk sizes (input channels staged per barrier pair)
+template <typename T, int KS, int STRIDE> struct KCof;
+template <> struct KCof<float, 1, 1> { static constexpr int v = 64; };
+template <> struct KCof<float, 3, 1> { static constexpr int v = 32; };
+template <> struct KCof<float, 3, 2> { static constexpr int v = 16; };
+template <> struct KCof<_Float16, 1, 1> { static constexpr int v = 128; };
+template <> struct KCof<_Float16, 3, 1> { static constexpr int v = 64; };
+template <> struct KCof<_Float16, 3, 2> { static constexpr int v = 32; };
+
+template <typename T, int KS, int STRIDE> struct Family {
+  static constexpr int KC = KCof<T, KS, STRIDE>::v;
+  static constexpr int MIW = STRIDE == 2 ? 2 : 4;   // wide: 2x2 waves
+  static constexpr int MIN = STRIDE == 2 ? 1 : 2;   // narrow: 4x1 waves
+  using Wide = Cfg<T, KS, STRIDE, 2, 2, MIW, 2, KC>;
+  using Narrow2 = Cfg<T, KS, STRIDE, 4, 1, MIN, 2, KC>;
+  using Narrow1 = Cfg<T, KS, STRIDE, 4, 1, MIN, 1, KC>;
+  static void init() { Wide::init(); Narrow2::init(); Narrow1::init(); }
+  static void launch(ConvArgs& a, Level* out_lvl, hipStream_t st) {
+    if (a.ntiles32 >= 3) Wide::launch(a, out_lvl, st);
+    else if (a.ntiles32 == 2) Narrow2::launch(a, out_lvl, st);
+    else Narrow1::launch(a, out_lvl, st);
+  }
+};
+
+template <typename T> void launch_t(ConvArgs& a, int k, int stride, Level* out_lvl, hipStream_t st) {
+  if (k == 1 && stride == 1) Family<T, 1, 1>::launch(a, out_lvl, st);
+  else if (k == 3 && stride == 1) Family<T, 3, 1>::launch(a, out_lvl, st);
+  else if (k == 3 && stride == 2) Family<T, 3, 2>::launch(a, out_lvl, st);
+  else fail(FFP_ERR_ARG, "conv: k=%d stride=%d has no kernel", k, stride);
+}
+
+}  // namespace
+
+void conv_kernels_init() {
+  static bool done = false;
+  if (done) return;
+  Family<float, 1, 1>::init(); Family<float, 3, 1>::init(); Family<float, 3, 2>::init();
+  Family<_Float16, 1, 1>::init(); Family<_Float16, 3, 1>::init(); Family<_Float16, 3, 2>::init();
+  done = true;
+}
+
+void launch_conv(const ConvOp& op, hipStream_t st) {
+  const PackedConv& pc = *op.pc;
+  FFP_CHECK(!pc.depthwise(), FFP_ERR_ARG, "conv %s: depthwise goes through launch_dwconv", pc.name.c_str());
+  FFP_CHECK(op.in.dt == pc.dt, FFP_ERR_ARG, "conv %s: input dtype differs from packed weights", pc.name.c_str());
+  FFP_CHECK(op.in.C == pc.cin && op.out.C == pc.cout, FFP_ERR_ARG, "conv %s: view channels (%d->%d) != weights (%d->%d)",
+            pc.name.c_str(), op.in.C, op.out.C, pc.cin, pc.cout);
+  const int epv = 16 / dsize(pc.dt);
+  FFP_CHECK(op.in.cs % epv == 0 && op.in.coff % epv == 0 && pc.cin % epv == 0, FFP_ERR_ARG,
+            "conv %s: input view not 16-byte aligned (cs=%d coff=%d cin=%d)", pc.name.c_str(), op.in.cs, op.in.coff, pc.cin);
+  FFP_CHECK(!(op.up && (pc.k != 3 || op.stride != 1)), FFP_ERR_ARG, "conv %s: upsampled input needs k3 s1", pc.name.c_str());
+  ConvArgs a{};
+  a.in = op.in.ptr; a.wpk = pc.w.p; a.bias = pc.bias.as<float>(); a.out = op.out.ptr;
+  a.res1 = op.has_res1 ? op.res1.ptr : nullptr;
+  a.res2 = op.has_res2 ? op.res2.ptr : nullptr;
+  a.in_tab = op.in.lvl->d_tab.as<int4>();
+  a.out_tab = op.out.lvl->d_tab.as<int4>();
+  a.tiles = nullptr;
+  a.total_px = op.out.lvl->total_px;
+  a.in_cs = op.in.cs; a.in_coff = op.in.coff; a.cin = pc.cin; a.cin_pad = pc.cin_pad;
+  a.out_cs = op.out.cs; a.out_coff = op.out.coff; a.cout = pc.cout;
+  a.r1_cs = op.res1.cs; a.r1_coff = op.res1.coff; a.r2_cs = op.res2.cs; a.r2_coff = op.res2.coff;
+  a.s1 = op.s1; a.s2 = op.s2;
+  a.act = op.act; a.out_f32 = (op.out.dt == F32) ? 1 : 0; a.up = op.up;
+  a.ncg = pc.ncg; a.ntiles32 = pc.cout_pad / 32;
+  bool vec = pc.cout % 4 == 0 && op.out.cs % 4 == 0 && op.out.coff % 4 == 0;
+  if (op.has_res1) {
+    FFP_CHECK(op.res1.dt == pc.dt, FFP_ERR_ARG, "conv %s: residual dtype", pc.name.c_str());
+    vec = vec && op.res1.cs % 4 == 0 && op.res1.coff % 4 == 0;
+  }
+  if (op.has_res2) {
+    FFP_CHECK(op.res2.dt == pc.dt, FFP_ERR_ARG, "conv %s: residual dtype", pc.name.c_str());
+    vec = vec && op.res2.cs % 4 == 0 && op.res2.coff % 4 == 0;
+  }
+  a.vec_ok = vec ? 1 : 0;
+  if (pc.k == 1) FFP_CHECK(op.in.lvl->total_px == op.out.lvl->total_px, FFP_ERR_ARG, "conv %s: 1x1 levels differ", pc.name.c_str());
+  if (pc.dt == F32) launch_t<float>(a, pc.k, op.stride, op.out.lvl, st);
+  else launch_t<_Float16>(a, pc.k, op.stride, op.out.lvl, st);
+  FFP_HIP(hipGetLastError());
+}
+
+}  // namespace ffp

@@ -1,0 +1,56 @@
+// engine.hpp — plans (a network laid out for one ragged batch shape), step lists and per-kernel profiling.
+#pragma once
+#include <functional>
+
+#include "common.hpp"
+#include "det_post.hpp"
+#include "ops.hpp"
+#include "weights.hpp"
+
+namespace ffp {
+
+// Per-launch HIP-event timing of convolution kernels, aggregated by kernel variant ("f32 k3s1 wide", ...).
+struct ConvProfile {
+  struct Entry { std::string variant; double flops = 0; double ms = 0; int launches = 0; };
+  bool enabled = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // recycled pool
+  struct Pending { int ev; std::string variant; double flops; };
+  std::vector<Pending> pending;
+  std::map<std::string, Entry> table;
+  ~ConvProfile();
+  void begin();                                  // clear the table, start collecting
+  int open(hipStream_t st);                      // record a start event, returns slot
+  void close(int slot, hipStream_t st, const std::string& variant, double flops);
+  void collect();                                // after the stream has drained
+};
+
+std::string conv_variant(const ConvOp& op);
+
+// One step of a plan. Kept as a closure: the op descriptors are fixed at plan build time.
+struct Step {
+  std::function<void(hipStream_t)> run;
+  bool is_conv = false;
+  std::string variant;
+  double flops = 0;
+};
+
+struct Plan {
+  std::vector<std::unique_ptr<Level>> levels;
+  std::vector<DevBuf> bufs;
+  std::vector<Step> steps;
+  double conv_flops = 0;
+  int conv_launches = 0;
+  size_t bytes = 0;
+
+  Level* add_level(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st);
+  TView alloc(Level* l, int C, DType dt);
+  void add_conv(const ConvOp& op);
+  void add(std::function<void(hipStream_t)> f) { Step s; s.run = std::move(f); steps.push_back(std::move(s)); }
+  void execute(hipStream_t st, ConvProfile* prof);
+};
+
+inline double conv_flops_of(const PackedConv& pc, int64_t out_px) {
+  return 2.0 * (double)(pc.cin_real / pc.groups) * pc.k * pc.k * (double)pc.cout * (double)out_px;
+}
+
+}  // namespace ffp

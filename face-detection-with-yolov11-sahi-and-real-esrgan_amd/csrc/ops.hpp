@@ -1,0 +1,58 @@
+// ops.hpp — host-side descriptors and launchers of the device operators (one launch covers a whole ragged batch).
+#pragma once
+#include "common.hpp"
+#include "weights.hpp"
+
+namespace ffp {
+
+// Dense convolution k in {1,3}, stride in {1,2}, pad k/2, as an implicit GEMM on MFMA (conv_mfma.hip).
+//   out = epilogue( conv(in) + bias ),   epilogue: act, then optional  v = v*s1 + res1,  v = v*s2 + res2
+// `up` = 1 reads the input through a nearest x2 upsample (ESRGAN conv_up1/2). Depthwise convs go to DwConvOp.
+struct ConvOp {
+  const PackedConv* pc = nullptr;
+  TView in, out;
+  int stride = 1;
+  int act = ACT_NONE;
+  int up = 0;
+  bool has_res1 = false, has_res2 = false;
+  TView res1, res2;
+  float s1 = 1.f, s2 = 1.f;
+  double flops = 0;   // 2*MAC, algorithmic (unpadded)
+};
+void launch_conv(const ConvOp& op, hipStream_t st);
+void conv_kernels_init();   // raise dynamic-LDS limits once per process
+
+// Depthwise 3x3, stride 1 (YOLO11 cls-tower DWConv and the PSA positional conv), fp32 math.
+// Input channel c is read from  in.coff + (c / grp) * grp_stride + grp_off + c % grp  (grp = C: identity) so that the
+// attention kernel's per-head [q|k|v] layout can be read in place.
+struct DwConvOp {
+  const PackedConv* pc = nullptr;
+  TView in, out;
+  int act = ACT_NONE;
+  int grp = 0, grp_stride = 0, grp_off = 0;
+  bool has_res = false;
+  TView res;
+};
+void launch_dwconv(const DwConvOp& op, hipStream_t st);
+
+// SPPF: y1,y2,y3 = 5x5/9x9/13x13 stride-1 max pools of `in` (== three chained MaxPool2d(5,1,2)), written to three slices.
+void launch_sppf_pool(const TView& in, const TView& y1, const TView& y2, const TView& y3, hipStream_t st);
+
+// nearest x2 upsample of `in` (level L) into `out` (level with doubled dims)
+void launch_upsample2x(const TView& in, const TView& out, hipStream_t st);
+
+// Multi-head attention of C2PSA: qkv [px][nh*(2kd+hd)] -> out [px][nh*hd] = softmax(q^T k * scale) applied to v.
+void launch_psa_attention(const TView& qkv, const TView& out, int nh, int kd, int hd, hipStream_t st);
+
+// ---- detector pre/post ------------------------------------------------------------------------------------
+struct LetterboxImg {     // one network input image cut from the frame
+  int x0, y0, sw, sh;     // source rect in the frame
+  int new_w, new_h;       // resized size
+  int top, left;          // padding
+  int net_h, net_w;       // = new + pads
+};
+// frame HxWx3 u8 (device) -> NHWC T with CPAD channels (3 used), /255, pad 114/255, optional channel flip.
+void launch_letterbox(const uint8_t* d_frame, int H, int W, int flip, const DevBuf& d_imgs /*LetterboxImg[n]*/,
+                      const TView& out, hipStream_t st);
+
+}  // namespace ffp

@@ -1,0 +1,316 @@
+// ops_misc.hip — the HBM-bound operators around the MFMA convolutions: depthwise 3x3, SPPF pooling, nearest x2,
+// C2PSA attention, LetterBox preprocessing. All work on ragged NHWC batches described by level tables.
+#include "ops.hpp"
+
+namespace ffp {
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v) { *p = (T)v; }
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+  if (act == ACT_SILU) return v / (1.0f + expf(-v));
+  if (act == ACT_LRELU) return v >= 0.f ? v : v * 0.2f;
+  return v;
+}
+
+// locate the image containing flat pixel `gp` (tables are tiny: linear scan from a per-thread guess is fine, binary here)
+__device__ __forceinline__ int find_img(const int4* tab, int n, long long gp) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((long long)tab[mid].x <= gp) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// ---- depthwise 3x3 s1 p1 --------------------------------------------------------------------------------------
+template <typename T>
+__global__ void dwconv3x3_kernel(const T* __restrict__ in, int in_cs, int in_coff, int grp, int grp_stride, int grp_off,
+                                 T* __restrict__ out, int out_cs, int out_coff, const float* __restrict__ w /*[9][C]*/,
+                                 const float* __restrict__ bias, const T* __restrict__ res, int r_cs, int r_coff, int C,
+                                 int act, const int4* __restrict__ tab, int n_img, long long total_px) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = total_px * C;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long long gp = idx / C;
+  const int im = find_img(tab, n_img, gp);
+  const int4 t = tab[im];
+  const int lp = (int)(gp - t.x), y = lp / t.z, x = lp - y * t.z;
+  const int cin = in_coff + (c / grp) * grp_stride + grp_off + (c % grp);
+  float acc = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = y + ky - 1;
+    if ((unsigned)yy >= (unsigned)t.y) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xx = x + kx - 1;
+      if ((unsigned)xx >= (unsigned)t.z) continue;
+      acc = fmaf(ldf(in + ((size_t)t.x + (size_t)yy * t.z + xx) * in_cs + cin), w[(ky * 3 + kx) * C + c], acc);
+    }
+  }
+  float v = act_fn(acc + bias[c], act);
+  if (res) v += ldf(res + (size_t)gp * r_cs + r_coff + c);
+  stf(out + (size_t)gp * out_cs + out_coff + c, v);
+}
+
+// ---- SPPF pooling: 5x5, 9x9, 13x13 windows (== 3 chained 5x5 pools with -inf padding) ----------------------------
+template <typename T>
+__global__ void sppf_pool_kernel(const T* __restrict__ in, int in_cs, int in_coff, T* __restrict__ y1, T* __restrict__ y2,
+                                 T* __restrict__ y3, int o_cs, int o1, int o2, int o3, int C, const int4* __restrict__ tab,
+                                 int n_img, long long total_px) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total_px * C) return;
+  const int c = (int)(idx % C);
+  const long long gp = idx / C;
+  const int im = find_img(tab, n_img, gp);
+  const int4 t = tab[im];
+  const int lp = (int)(gp - t.x), y = lp / t.z, x = lp - y * t.z;
+  float m5 = -INFINITY, m9 = -INFINITY, m13 = -INFINITY;
+  for (int dy = -6; dy <= 6; ++dy) {
+    const int yy = y + dy;
+    if ((unsigned)yy >= (unsigned)t.y) continue;
+    for (int dx = -6; dx <= 6; ++dx) {
+      const int xx = x + dx;
+      if ((unsigned)xx >= (unsigned)t.z) continue;
+      const float v = ldf(in + ((size_t)t.x + (size_t)yy * t.z + xx) * in_cs + in_coff + c);
+      const int r = max(abs(dy), abs(dx));
+      m13 = fmaxf(m13, v);
+      if (r <= 4) m9 = fmaxf(m9, v);
+      if (r <= 2) m5 = fmaxf(m5, v);
+    }
+  }
+  stf(y1 + (size_t)gp * o_cs + o1 + c, m5);
+  stf(y2 + (size_t)gp * o_cs + o2 + c, m9);
+  stf(y3 + (size_t)gp * o_cs + o3 + c, m13);
+}
+
+// ---- nearest x2 ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void upsample2x_kernel(const T* __restrict__ in, int in_cs, int in_coff, const int4* __restrict__ in_tab,
+                                  T* __restrict__ out, int out_cs, int out_coff, const int4* __restrict__ out_tab, int n_img,
+                                  int C, long long total_out_px) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total_out_px * C) return;
+  const int c = (int)(idx % C);
+  const long long gp = idx / C;
+  const int im = find_img(out_tab, n_img, gp);
+  const int4 to = out_tab[im], ti = in_tab[im];
+  const int lp = (int)(gp - to.x), y = lp / to.z, x = lp - y * to.z;
+  out[(size_t)gp * out_cs + out_coff + c] = in[((size_t)ti.x + (size_t)(y >> 1) * ti.z + (x >> 1)) * in_cs + in_coff + c];
+}
+
+// ---- C2PSA attention ----------------------------------------------------------------------------------------------
+// grid (ceil(Nmax/256), nh, n_img), 256 threads: one query per thread, keys/values streamed through LDS 64 at a time,
+// fp32 online softmax. qkv pixel record per head: [q(kd) | k(kd) | v(hd)].
+template <typename T, int KD, int HD>
+__global__ void __launch_bounds__(256) psa_attention_kernel(const T* __restrict__ qkv, int q_cs, int q_coff,
+                                                            T* __restrict__ out, int o_cs, int o_coff,
+                                                            const int4* __restrict__ tab, float scale) {
+  constexpr int KB = 64;
+  __shared__ float ks[KB][KD];
+  __shared__ float vs[KB][HD];
+  const int4 t = tab[blockIdx.z];
+  const int N = t.y * t.z;
+  const int head = blockIdx.y;
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= N) return;
+  const int hoff = q_coff + head * (2 * KD + HD);
+  float q[KD];
+  const bool active = qi < N;
+  {
+    const T* qp = qkv + ((size_t)t.x + (active ? qi : 0)) * q_cs + hoff;
+#pragma unroll
+    for (int d = 0; d < KD; ++d) q[d] = ldf(qp + d);
+  }
+  float m = -INFINITY, l = 0.f;
+  float o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+  for (int j0 = 0; j0 < N; j0 += KB) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < KB * (KD + HD); i += 256) {
+      const int j = i / (KD + HD), d = i - j * (KD + HD);
+      float v = 0.f;
+      if (j0 + j < N) v = ldf(qkv + ((size_t)t.x + j0 + j) * q_cs + hoff + KD + d);
+      if (d < KD) ks[j][d] = v; else vs[j][d - KD] = v;
+    }
+    __syncthreads();
+    const int jn = min(KB, N - j0);
+    for (int j = 0; j < jn; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < KD; ++d) s = fmaf(q[d], ks[j][d], s);
+      s *= scale;
+      if (s > m) {
+        const float f = expf(m - s);
+        l *= f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] *= f;
+        m = s;
+      }
+      const float pj = expf(s - m);
+      l += pj;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] = fmaf(pj, vs[j][d], o[d]);
+    }
+  }
+  if (!active) return;
+  const float inv = 1.0f / l;
+  T* op = out + ((size_t)t.x + qi) * o_cs + o_coff + head * HD;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) stf(op + d, o[d] * inv);
+}
+
+// ---- LetterBox + normalise ------------------------------------------------------------------------------------------
+// cv2.resize INTER_LINEAR for uint8 restated in fixed point (11-bit coefficients, two-pass rounding), pad value 114,
+// /255, optional channel flip, NHWC with CPAD channels (>= 3, rest zero).
+__device__ __forceinline__ void lin_coef(int d, double scale, int n_src, bool zero_at_border, int& s, int& c0, int& c1) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int si = (int)floorf(f);
+  f -= (float)si;
+  if (zero_at_border) {
+    if (si < 0) { f = 0.f; si = 0; }
+    if (si >= n_src - 1) { f = 0.f; si = n_src - 1; }
+  }
+  s = si;
+  c0 = (int)rintf((1.0f - f) * 2048.0f);
+  c1 = (int)rintf(f * 2048.0f);
+}
+
+template <typename T, int CPAD>
+__global__ void letterbox_kernel(const uint8_t* __restrict__ frame, int W, int flip, const LetterboxImg* __restrict__ imgs,
+                                 const int4* __restrict__ tab, int n_img, T* __restrict__ out, long long total_px) {
+  const long long gp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gp >= total_px) return;
+  const int im = find_img(tab, n_img, gp);
+  const int4 t = tab[im];
+  const LetterboxImg L = imgs[im];
+  const int lp = (int)(gp - t.x), y = lp / t.z, x = lp - y * t.z;
+  int px[3] = {114, 114, 114};
+  const int ry = y - L.top, rx = x - L.left;
+  if (ry >= 0 && ry < L.new_h && rx >= 0 && rx < L.new_w) {
+    const uint8_t* src = frame + ((size_t)L.y0 * W + L.x0) * 3;
+    const size_t rs = (size_t)W * 3;
+    if (L.new_w == L.sw && L.new_h == L.sh) {
+      const uint8_t* p = src + (size_t)ry * rs + (size_t)rx * 3;
+      px[0] = p[0]; px[1] = p[1]; px[2] = p[2];
+    } else {
+      int sx, ax0, ax1, sy, by0, by1;
+      lin_coef(rx, (double)L.sw / (double)L.new_w, L.sw, true, sx, ax0, ax1);
+      lin_coef(ry, (double)L.sh / (double)L.new_h, L.sh, false, sy, by0, by1);
+      const int sx1 = min(sx + 1, L.sw - 1);
+      const int y0 = min(max(sy, 0), L.sh - 1), y1 = min(max(sy + 1, 0), L.sh - 1);
+      const uint8_t* r0 = src + (size_t)y0 * rs;
+      const uint8_t* r1 = src + (size_t)y1 * rs;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int S0 = r0[sx * 3 + c] * ax0 + r0[sx1 * 3 + c] * ax1;
+        const int S1 = r1[sx * 3 + c] * ax0 + r1[sx1 * 3 + c] * ax1;
+        const int v = (((by0 * (S0 >> 4)) >> 16) + ((by1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        px[c] = min(max(v, 0), 255);
+      }
+    }
+  }
+  T* op = out + (size_t)gp * CPAD;
+  const float v0 = (float)px[flip ? 2 : 0] / 255.0f, v1 = (float)px[1] / 255.0f, v2 = (float)px[flip ? 0 : 2] / 255.0f;
+  stf(op + 0, v0); stf(op + 1, v1); stf(op + 2, v2);
+#pragma unroll
+  for (int c = 3; c < CPAD; ++c) stf(op + c, 0.f);
+}
+
+inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+void launch_dwconv(const DwConvOp& op, hipStream_t st) {
+  const PackedConv& pc = *op.pc;
+  FFP_CHECK(pc.depthwise() && pc.k == 3, FFP_ERR_ARG, "dwconv %s: expects depthwise 3x3", pc.name.c_str());
+  const int C = pc.cout;
+  FFP_CHECK(op.out.C == C && op.in.lvl == op.out.lvl, FFP_ERR_ARG, "dwconv %s: view mismatch", pc.name.c_str());
+  const int grp = op.grp > 0 ? op.grp : C;
+  const int gstride = op.grp > 0 ? op.grp_stride : C;
+  const long long total = op.out.lvl->total_px * C;
+  const int4* tab = op.out.lvl->d_tab.as<int4>();
+  const unsigned nb = blocks_for(total, 256);
+  if (op.in.dt == F32)
+    hipLaunchKernelGGL(dwconv3x3_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)op.in.ptr, op.in.cs, op.in.coff, grp,
+                       gstride, op.grp_off, (float*)op.out.ptr, op.out.cs, op.out.coff, pc.w.as<float>(), pc.bias.as<float>(),
+                       op.has_res ? (const float*)op.res.ptr : nullptr, op.res.cs, op.res.coff, C, op.act, tab, op.out.lvl->n,
+                       op.out.lvl->total_px);
+  else
+    hipLaunchKernelGGL(dwconv3x3_kernel<_Float16>, dim3(nb), dim3(256), 0, st, (const _Float16*)op.in.ptr, op.in.cs, op.in.coff,
+                       grp, gstride, op.grp_off, (_Float16*)op.out.ptr, op.out.cs, op.out.coff, pc.w.as<float>(),
+                       pc.bias.as<float>(), op.has_res ? (const _Float16*)op.res.ptr : nullptr, op.res.cs, op.res.coff, C, op.act,
+                       tab, op.out.lvl->n, op.out.lvl->total_px);
+  FFP_HIP(hipGetLastError());
+}
+
+void launch_sppf_pool(const TView& in, const TView& y1, const TView& y2, const TView& y3, hipStream_t st) {
+  FFP_CHECK(y1.ptr == y2.ptr && y2.ptr == y3.ptr && y1.cs == y2.cs && y2.cs == y3.cs, FFP_ERR_ARG, "sppf: outputs must be slices of one buffer");
+  const int C = in.C;
+  const long long total = in.lvl->total_px * C;
+  const unsigned nb = blocks_for(total, 256);
+  const int4* tab = in.lvl->d_tab.as<int4>();
+  if (in.dt == F32)
+    hipLaunchKernelGGL(sppf_pool_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)in.ptr, in.cs, in.coff, (float*)y1.ptr,
+                       (float*)y2.ptr, (float*)y3.ptr, y1.cs, y1.coff, y2.coff, y3.coff, C, tab, in.lvl->n, in.lvl->total_px);
+  else
+    hipLaunchKernelGGL(sppf_pool_kernel<_Float16>, dim3(nb), dim3(256), 0, st, (const _Float16*)in.ptr, in.cs, in.coff,
+                       (_Float16*)y1.ptr, (_Float16*)y2.ptr, (_Float16*)y3.ptr, y1.cs, y1.coff, y2.coff, y3.coff, C, tab, in.lvl->n,
+                       in.lvl->total_px);
+  FFP_HIP(hipGetLastError());
+}
+
+void launch_upsample2x(const TView& in, const TView& out, hipStream_t st) {
+  FFP_CHECK(in.C == out.C && in.dt == out.dt && in.lvl->n == out.lvl->n, FFP_ERR_ARG, "upsample: view mismatch");
+  const long long total = out.lvl->total_px * in.C;
+  const unsigned nb = blocks_for(total, 256);
+  if (in.dt == F32)
+    hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)in.ptr, in.cs, in.coff,
+                       in.lvl->d_tab.as<int4>(), (float*)out.ptr, out.cs, out.coff, out.lvl->d_tab.as<int4>(), out.lvl->n, in.C,
+                       out.lvl->total_px);
+  else
+    hipLaunchKernelGGL(upsample2x_kernel<_Float16>, dim3(nb), dim3(256), 0, st, (const _Float16*)in.ptr, in.cs, in.coff,
+                       in.lvl->d_tab.as<int4>(), (_Float16*)out.ptr, out.cs, out.coff, out.lvl->d_tab.as<int4>(), out.lvl->n,
+                       in.C, out.lvl->total_px);
+  FFP_HIP(hipGetLastError());
+}
+
+void launch_psa_attention(const TView& qkv, const TView& out, int nh, int kd, int hd, hipStream_t st) {
+  FFP_CHECK(kd == 32 && hd == 64, FFP_ERR_ARG, "psa attention: only key_dim 32 / head_dim 64 (YOLO11 n/s) is instantiated");
+  FFP_CHECK(qkv.C == nh * (2 * kd + hd) && out.C == nh * hd && qkv.lvl == out.lvl, FFP_ERR_ARG, "psa attention: view mismatch");
+  int nmax = 0;
+  for (int i = 0; i < qkv.lvl->n; ++i) nmax = std::max(nmax, qkv.lvl->h[i] * qkv.lvl->w[i]);
+  dim3 grid((nmax + 255) / 256, nh, qkv.lvl->n);
+  const float scale = 1.0f / sqrtf((float)kd);
+  if (qkv.dt == F32)
+    hipLaunchKernelGGL((psa_attention_kernel<float, 32, 64>), grid, dim3(256), 0, st, (const float*)qkv.ptr, qkv.cs, qkv.coff,
+                       (float*)out.ptr, out.cs, out.coff, qkv.lvl->d_tab.as<int4>(), scale);
+  else
+    hipLaunchKernelGGL((psa_attention_kernel<_Float16, 32, 64>), grid, dim3(256), 0, st, (const _Float16*)qkv.ptr, qkv.cs,
+                       qkv.coff, (_Float16*)out.ptr, out.cs, out.coff, qkv.lvl->d_tab.as<int4>(), scale);
+  FFP_HIP(hipGetLastError());
+}
+
+void launch_letterbox(const uint8_t* d_frame, int H, int W, int flip, const DevBuf& d_imgs, const TView& out, hipStream_t st) {
+  (void)H;
+  const long long total = out.lvl->total_px;
+  const unsigned nb = blocks_for(total, 256);
+  FFP_CHECK(out.coff == 0 && out.cs == out.C, FFP_ERR_ARG, "letterbox: output must be a whole buffer");
+  if (out.dt == F32) {
+    FFP_CHECK(out.C == 4, FFP_ERR_ARG, "letterbox: fp32 output has 4 channels");
+    hipLaunchKernelGGL((letterbox_kernel<float, 4>), dim3(nb), dim3(256), 0, st, d_frame, W, flip, d_imgs.as<LetterboxImg>(),
+                       out.lvl->d_tab.as<int4>(), out.lvl->n, (float*)out.ptr, total);
+  } else {
+    FFP_CHECK(out.C == 8, FFP_ERR_ARG, "letterbox: fp16 output has 8 channels");
+    hipLaunchKernelGGL((letterbox_kernel<_Float16, 8>), dim3(nb), dim3(256), 0, st, d_frame, W, flip, d_imgs.as<LetterboxImg>(),
+                       out.lvl->d_tab.as<int4>(), out.lvl->n, (_Float16*)out.ptr, total);
+  }
+  FFP_HIP(hipGetLastError());
+}
+
+}  // namespace ffp

@@ -1,0 +1,69 @@
+// sr_ops.hpp — Real-ESRGAN pre/post kernels (sr_ops.hip) and the SR engine (rrdb.cpp).
+#pragma once
+#include "engine.hpp"
+
+namespace ffp {
+
+struct SrSrc {          // where one network tile reads its pixels
+  long long src_off;    // byte offset of the source image inside the base allocation
+  int src_stride;       // bytes per source row
+  int src_h, src_w;     // source size
+  int pre_h, pre_w;     // size after pre_pad; rows beyond reflect about it first (mod pad), then about the source
+  int x0, y0;           // tile origin in padded-source coordinates
+};
+struct SrDst {          // where the core of one tile's output lands
+  long long dst_off;    // byte offset of the output canvas inside the base allocation
+  int dst_stride;       // bytes per canvas row
+  int ox, oy;           // core origin in the canvas
+  int cw, ch;           // core size (output pixels)
+  int tx, ty;           // core origin inside the tile's network output
+};
+
+void launch_sr_pre(const uint8_t* d_base, const SrSrc* d_srcs, const TView& out, int shuf, hipStream_t st);
+void launch_sr_post(const TView& net_out, const SrDst* d_dsts, const long long* d_core_off, long long total_core, uint8_t* d_base,
+                    hipStream_t st);
+void launch_crop_gather(const uint8_t* d_frame, int W, const int4* d_boxes, const long long* d_offs, int n, uint8_t* d_out,
+                        hipStream_t st);
+
+struct SrPlan : Plan {
+  Level* Lb = nullptr;     // body level (input res, or half res for x2)
+  Level* L1 = nullptr;     // x2 of body
+  Level* L2 = nullptr;     // x4 of body
+  TView input, out;
+  DevBuf d_srcs, d_dsts, d_core_off;
+};
+
+struct SrImage {           // one image of a batch: offsets are relative to the in/out base allocations
+  long long in_off; int in_stride; int h, w;
+  long long out_off; int out_stride;
+};
+
+class SrEngine {
+ public:
+  SrEngine(const void* weights, size_t nbytes, int scale, int num_block, int device, int half);
+  ~SrEngine();
+  int scale() const { return scale_; }
+  int device() const { return device_; }
+  hipStream_t stream() const { return st_; }
+  // all images live in device memory: inputs at d_in + in_off (BGR u8, in_stride bytes/row), outputs at d_out + out_off
+  void enhance_dev(const uint8_t* d_in, uint8_t* d_out, const std::vector<SrImage>& imgs, int tile, int tile_pad, int pre_pad);
+
+  DevBuf scratch_in, scratch_out, scratch_boxes, scratch_offs;
+  ConvProfile prof;
+  float last_ms = 0.f;
+  double last_conv_flops = 0;
+  int last_conv_launches = 0;
+
+ private:
+  struct TileDesc { SrSrc src; SrDst dst; int h, w; };
+  void build_plan(SrPlan& P, const std::vector<int>& hs, const std::vector<int>& ws);
+  const PackedConv* conv(const std::string& name) const;
+  std::map<std::string, PackedConv> convs_;
+  std::map<std::vector<int>, std::unique_ptr<SrPlan>> plans_;
+  int scale_ = 4, num_block_ = 23, device_ = 0;
+  DType dt_ = F16;
+  hipStream_t st_ = nullptr;
+  hipEvent_t ev_[2];
+};
+
+}  // namespace ffp

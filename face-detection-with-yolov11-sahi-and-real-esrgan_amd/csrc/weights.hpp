@@ -1,0 +1,44 @@
+// weights.hpp — FFPW container parsing and repacking of OIHW fp32 weights into the MFMA fragment layout.
+#pragma once
+#include "common.hpp"
+
+namespace ffp {
+
+struct HostTensor {
+  const float* data = nullptr;
+  std::vector<int> dims;
+  size_t numel() const { size_t n = 1; for (int d : dims) n *= (size_t)d; return n; }
+};
+
+// Parsed FFPW container (weights_io.py). Does not own the bytes.
+struct WeightFile {
+  std::map<std::string, HostTensor> t;
+  void parse(const void* bytes, size_t n);
+  const HostTensor& get(const std::string& name) const;
+  bool has(const std::string& name) const { return t.count(name) != 0; }
+};
+
+// One convolution's parameters on the device.
+//  groups == 1 : `w` holds MFMA A-operand fragments, [ntile32][tap][cgroup][lane 0..63][16 bytes]
+//                 fp16: cgroup = 16 input channels, lane l element j -> (n = 32*ntile + (l&31), c = 16*cg + 8*(l>>5) + j)
+//                 fp32: cgroup =  8 input channels, lane l element j -> (n = 32*ntile + (l&31), c =  8*cg + 4*(l>>5) + j)
+//                 zero padded in both n and c.
+//  depthwise   : `w` holds fp32 [tap][C].
+//  bias: fp32, padded to cout_pad.
+struct PackedConv {
+  std::string name;
+  int cin = 0, cout = 0, k = 1, groups = 1;   // cin is padded up to a 16-byte multiple of the element type
+  int cin_real = 0;                            // channels that carry weights (FLOP accounting)
+  int cin_pad = 0, cout_pad = 0, ncg = 0;
+  DType dt = F32;
+  DevBuf w, bias;
+  bool depthwise() const { return groups > 1; }
+};
+
+// w: (cout, cin/groups, k, k) fp32 OIHW, b: (cout) or null (zeros)
+void pack_conv(PackedConv& pc, const std::string& name, const float* w, const float* b, int cout, int cin, int k,
+               int groups, DType dt, hipStream_t st);
+void pack_conv(PackedConv& pc, const WeightFile& wf, const std::string& name, int k, int groups, DType dt,
+               hipStream_t st);
+
+}  // namespace ffp

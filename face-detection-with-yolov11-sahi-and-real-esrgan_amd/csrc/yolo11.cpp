@@ -1,0 +1,401 @@
+// yolo11.cpp — YOLO11{n,s}-pose as a plan of HIP launches over a ragged batch of crops.
+//
+// Graph: Ultralytics `yolo11-pose.yaml`; the reference reaches it through
+// `self.model.predict(...)` at utils/yolo_wrapper.py:74-80. Every Concat is virtual: producers write straight into
+// channel slices of the consumer's buffer; Upsample is a copy into such a slice.
+#include "yolo11.hpp"
+
+#include <cmath>
+
+namespace ffp {
+
+namespace {
+int make_div8(double x) { return (int)std::ceil(x / 8.0) * 8; }
+}  // namespace
+
+void letterbox_geometry(int h, int w, int imgsz, int32_t* o) {
+  // Ultralytics LetterBox(new_shape=imgsz, auto=True, scaleup=True, center=True, stride=32); Python round() is
+  // round-half-even, as is nearbyint() under the default rounding mode.
+  const double r = std::min((double)imgsz / h, (double)imgsz / w);
+  const int new_w = (int)std::nearbyint(w * r), new_h = (int)std::nearbyint(h * r);
+  double dw = (double)((imgsz - new_w) % 32), dh = (double)((imgsz - new_h) % 32);
+  if (dw < 0) dw += 32;
+  if (dh < 0) dh += 32;
+  dw /= 2; dh /= 2;
+  o[0] = new_w; o[1] = new_h;
+  o[2] = (int)std::nearbyint(dh - 0.1); o[3] = (int)std::nearbyint(dh + 0.1);
+  o[4] = (int)std::nearbyint(dw - 0.1); o[5] = (int)std::nearbyint(dw + 0.1);
+}
+
+DetEngine::DetEngine(const void* weights, size_t nbytes, int arch, int nc, int nkpt, int device, int precision) {
+  FFP_CHECK(arch == 'n' || arch == 's', FFP_ERR_ARG, "arch must be 'n' or 's'");
+  FFP_CHECK(nc >= 1 && nc <= 256 && nkpt >= 0 && nkpt <= 32, FFP_ERR_ARG, "nc/nkpt out of range");
+  FFP_CHECK(precision == FFP_PREC_F32 || precision == FFP_PREC_F16, FFP_ERR_ARG, "precision");
+  int ndev = 0;
+  FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0, FFP_ERR_HIP, "no HIP device available (the detector has no CPU path)");
+  FFP_CHECK(device >= 0 && device < ndev, FFP_ERR_ARG, "device %d of %d", device, ndev);
+  device_ = device; nc_ = nc; nkpt_ = nkpt; scale_ = (char)arch; dt_ = precision == FFP_PREC_F16 ? F16 : F32;
+  FFP_HIP(hipSetDevice(device_));
+  FFP_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  for (auto& e : ev_) FFP_HIP(hipEventCreate(&e));
+  conv_kernels_init();
+  WeightFile wf;
+  wf.parse(weights, nbytes);
+  for (const auto& kv : wf.t) {
+    const std::string& nm = kv.first;
+    if (nm.size() < 7 || nm.compare(nm.size() - 7, 7, ".weight") != 0) continue;
+    const std::string base = nm.substr(0, nm.size() - 7);
+    const HostTensor& w = kv.second;
+    FFP_CHECK(w.dims.size() == 4 && w.dims[2] == w.dims[3], FFP_ERR_WEIGHTS, "%s: not a conv weight", nm.c_str());
+    const int k = w.dims[2];
+    const int groups = (w.dims[1] == 1 && w.dims[0] > 1 && k == 3) ? w.dims[0] : 1;
+    pack_conv(convs_[base], wf, base, k, groups, dt_, st_);   // input channels are zero-padded to a 16-byte multiple
+  }
+  FFP_CHECK(convs_.count("model.0.conv") && convs_.count("model.23.cv2.0.2"), FFP_ERR_WEIGHTS,
+            "container does not hold YOLO11-pose tensors");
+  FFP_CHECK(conv("model.23.cv3.0.2")->cout == nc_ && conv("model.23.cv4.0.2")->cout == 3 * nkpt_, FFP_ERR_WEIGHTS,
+            "head shapes (%d classes, %d kpt values) differ from nc=%d nkpt=%d", conv("model.23.cv3.0.2")->cout,
+            conv("model.23.cv4.0.2")->cout, nc_, nkpt_);
+}
+
+DetEngine::~DetEngine() {
+  (void)hipSetDevice(device_);
+  if (st_) (void)hipStreamSynchronize(st_);
+  plans_.clear();
+  convs_.clear();
+  for (auto& e : ev_) (void)hipEventDestroy(e);
+  if (st_) (void)hipStreamDestroy(st_);
+}
+
+const PackedConv* DetEngine::conv(const std::string& name) const {
+  auto it = convs_.find(name);
+  FFP_CHECK(it != convs_.end(), FFP_ERR_WEIGHTS, "conv '%s' missing from the weight container", name.c_str());
+  return &it->second;
+}
+
+void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::vector<int>& ws) {
+  const int n = (int)hs.size();
+  for (int l = 0; l < 6; ++l) {
+    std::vector<int> h(n), w(n);
+    for (int i = 0; i < n; ++i) { h[i] = hs[i] >> l; w[i] = ws[i] >> l; }
+    P.L[l] = P.add_level(h, w, st_);
+  }
+  const double width = scale_ == 'n' ? 0.25 : 0.50;
+  auto ch = [&](int c) { return make_div8(std::min(c, 1024) * width); };
+  const int c64 = ch(64), c128 = ch(128), c256 = ch(256), c512 = ch(512), c1024 = ch(1024);
+  const DType T = dt_;
+
+  auto cv = [&](const std::string& name, const TView& in, const TView& out, int stride, int act, const TView* res = nullptr) {
+    ConvOp o;
+    o.pc = conv(name); o.in = in; o.out = out; o.stride = stride; o.act = act;
+    if (res) { o.has_res1 = true; o.res1 = *res; o.s1 = 1.f; }
+    FFP_CHECK(o.pc->cin == in.C && o.pc->cout == out.C, FFP_ERR_WEIGHTS, "%s: weights are %d->%d, graph expects %d->%d",
+              name.c_str(), o.pc->cin, o.pc->cout, in.C, out.C);
+    P.add_conv(o);
+  };
+  auto dw = [&](const std::string& name, const TView& in, const TView& out, int act) {
+    DwConvOp o;
+    o.pc = conv(name); o.in = in; o.out = out; o.act = act;
+    P.add([o](hipStream_t s) { launch_dwconv(o, s); });
+  };
+  // Bottleneck(c, c, shortcut, k=(3,3)): out = x + cv2(cv1(x))
+  auto bottleneck = [&](const std::string& p, const TView& x, const TView& out, int chid) {
+    TView t = P.alloc(x.lvl, chid, T);
+    cv(p + ".cv1.conv", x, t, 1, ACT_SILU);
+    cv(p + ".cv2.conv", t, out, 1, ACT_SILU, &x);
+  };
+  // C3k2(c1, c2, n=1, c3k, e): cat = [a | b | m(b)]; out = cv2(cat)
+  auto c3k2 = [&](const std::string& p, const TView& in, const TView& out, int c2, bool c3k, double e) {
+    const int c = (int)(c2 * e);
+    TView cat = P.alloc(in.lvl, 3 * c, T);
+    cv(p + ".cv1.conv", in, cat.slice(0, 2 * c), 1, ACT_SILU);
+    const TView b = cat.slice(c, c), mo = cat.slice(2 * c, c);
+    if (!c3k) {
+      bottleneck(p + ".m.0", b, mo, c / 2);
+    } else {     // C3k(c, c, n=2): cv3(cat(m(cv1(x)), cv2(x)))
+      const int c_ = c / 2;
+      TView cat2 = P.alloc(in.lvl, 2 * c_, T);
+      TView a0 = P.alloc(in.lvl, c_, T), a1 = P.alloc(in.lvl, c_, T);
+      cv(p + ".m.0.cv1.conv", b, a0, 1, ACT_SILU);
+      bottleneck(p + ".m.0.m.0", a0, a1, c_);
+      bottleneck(p + ".m.0.m.1", a1, cat2.slice(0, c_), c_);
+      cv(p + ".m.0.cv2.conv", b, cat2.slice(c_, c_), 1, ACT_SILU);
+      cv(p + ".m.0.cv3.conv", cat2, mo, 1, ACT_SILU);
+    }
+    cv(p + ".cv2.conv", cat, out, 1, ACT_SILU);
+  };
+
+  // ---- buffers that realise the Concat layers --------------------------------------------------------------------
+  const int cin0 = T == F16 ? 8 : 4;
+  P.input = P.alloc(P.L[0], cin0, T);
+  TView cat12 = P.alloc(P.L[4], c1024 + c512, T);   // [up(x10) | x6]
+  TView cat15 = P.alloc(P.L[3], c512 + c512, T);    // [up(x13) | x4]
+  TView cat18 = P.alloc(P.L[4], c256 + c512, T);    // [conv17(x16) | x13]
+  TView cat21 = P.alloc(P.L[5], c512 + c1024, T);   // [conv20(x19) | x10]
+  const TView x6 = cat12.slice(c1024, c512), x4 = cat15.slice(c512, c512);
+  const TView x13 = cat18.slice(c256, c512), x10 = cat21.slice(c512, c1024);
+
+  // ---- backbone --------------------------------------------------------------------------------------------------------
+  TView x0 = P.alloc(P.L[1], c64, T);
+  cv("model.0.conv", P.input, x0, 2, ACT_SILU);   // stem reads the 4/8-channel padded image (weights zero padded at pack)
+  TView x1 = P.alloc(P.L[2], c128, T);
+  cv("model.1.conv", x0, x1, 2, ACT_SILU);
+  TView x2 = P.alloc(P.L[2], c256, T);
+  c3k2("model.2", x1, x2, c256, false, 0.25);
+  TView x3 = P.alloc(P.L[3], c256, T);
+  cv("model.3.conv", x2, x3, 2, ACT_SILU);
+  c3k2("model.4", x3, x4, c512, false, 0.25);
+  TView x5 = P.alloc(P.L[4], c512, T);
+  cv("model.5.conv", x4, x5, 2, ACT_SILU);
+  c3k2("model.6", x5, x6, c512, true, 0.5);
+  TView x7 = P.alloc(P.L[5], c1024, T);
+  cv("model.7.conv", x6, x7, 2, ACT_SILU);
+  TView x8 = P.alloc(P.L[5], c1024, T);
+  c3k2("model.8", x7, x8, c1024, true, 0.5);
+  // SPPF
+  {
+    const int c_ = c1024 / 2;
+    TView cat9 = P.alloc(P.L[5], 4 * c_, T);
+    cv("model.9.cv1.conv", x8, cat9.slice(0, c_), 1, ACT_SILU);
+    const TView y0 = cat9.slice(0, c_), y1 = cat9.slice(c_, c_), y2 = cat9.slice(2 * c_, c_), y3 = cat9.slice(3 * c_, c_);
+    P.add([y0, y1, y2, y3](hipStream_t s) { launch_sppf_pool(y0, y1, y2, y3, s); });
+    TView x9 = P.alloc(P.L[5], c1024, T);
+    cv("model.9.cv2.conv", cat9, x9, 1, ACT_SILU);
+    // C2PSA
+    const int h = c1024 / 2, nh = h / 64, hd = h / nh, kd = hd / 2;
+    TView pb = P.alloc(P.L[5], 2 * h, T);
+    cv("model.10.cv1.conv", x9, pb, 1, ACT_SILU);
+    const TView b = pb.slice(h, h);
+    TView qkv = P.alloc(P.L[5], nh * (2 * kd + hd), T);
+    cv("model.10.m.0.attn.qkv.conv", b, qkv, 1, ACT_NONE);
+    TView ao = P.alloc(P.L[5], h, T);
+    P.add([qkv, ao, nh, kd, hd](hipStream_t s) { launch_psa_attention(qkv, ao, nh, kd, hd, s); });
+    TView xa = P.alloc(P.L[5], h, T);
+    {
+      DwConvOp o;
+      o.pc = conv("model.10.m.0.attn.pe.conv");
+      o.in = qkv; o.in.C = h; o.out = xa; o.act = ACT_NONE;
+      o.grp = hd; o.grp_stride = 2 * kd + hd; o.grp_off = 2 * kd;
+      o.has_res = true; o.res = ao;
+      P.add([o](hipStream_t s) { launch_dwconv(o, s); });
+    }
+    TView b2 = P.alloc(P.L[5], h, T);
+    cv("model.10.m.0.attn.proj.conv", xa, b2, 1, ACT_NONE, &b);
+    TView f1 = P.alloc(P.L[5], 2 * h, T);
+    cv("model.10.m.0.ffn.0.conv", b2, f1, 1, ACT_SILU);
+    cv("model.10.m.0.ffn.1.conv", f1, b, 1, ACT_NONE, &b2);
+    cv("model.10.cv2.conv", pb, x10, 1, ACT_SILU);
+  }
+  // ---- neck ------------------------------------------------------------------------------------------------------------
+  {
+    const TView up = cat12.slice(0, c1024);
+    P.add([x10, up](hipStream_t s) { launch_upsample2x(x10, up, s); });
+  }
+  c3k2("model.13", cat12, x13, c512, false, 0.5);
+  {
+    const TView up = cat15.slice(0, c512);
+    P.add([x13, up](hipStream_t s) { launch_upsample2x(x13, up, s); });
+  }
+  TView x16 = P.alloc(P.L[3], c256, T);
+  c3k2("model.16", cat15, x16, c256, false, 0.5);
+  cv("model.17.conv", x16, cat18.slice(0, c256), 2, ACT_SILU);
+  TView x19 = P.alloc(P.L[4], c512, T);
+  c3k2("model.19", cat18, x19, c512, false, 0.5);
+  cv("model.20.conv", x19, cat21.slice(0, c512), 2, ACT_SILU);
+  TView x22 = P.alloc(P.L[5], c1024, T);
+  c3k2("model.22", cat21, x22, c1024, true, 0.5);
+
+  // ---- Pose head: per level one fp32 record [64 DFL | nc | 3*nkpt] per pixel ---------------------------------------------
+  const TView feats[3] = {x16, x19, x22};
+  const int chs[3] = {c256, c512, c1024};
+  const int nk = 3 * nkpt_;
+  const int no = 64 + nc_ + nk;
+  const int head_cs = (no + 3) / 4 * 4;
+  const int c2 = std::max(std::max(16, chs[0] / 4), 64);
+  const int c3 = std::max(chs[0], std::min(nc_, 100));
+  const int c4 = std::max(chs[0] / 4, nk);
+  for (int l = 0; l < 3; ++l) {
+    Level* lv = P.L[3 + l];
+    P.head[l] = P.alloc(lv, head_cs, F32);
+    const std::string p = "model.23";
+    const std::string ls = std::to_string(l);
+    const TView& x = feats[l];
+    TView t1 = P.alloc(lv, c2, T), t2 = P.alloc(lv, c2, T);
+    cv(p + ".cv2." + ls + ".0.conv", x, t1, 1, ACT_SILU);
+    cv(p + ".cv2." + ls + ".1.conv", t1, t2, 1, ACT_SILU);
+    cv(p + ".cv2." + ls + ".2", t2, P.head[l].slice(0, 64), 1, ACT_NONE);
+    TView d1 = P.alloc(lv, chs[l], T), e1 = P.alloc(lv, c3, T), d2 = P.alloc(lv, c3, T), e2 = P.alloc(lv, c3, T);
+    dw(p + ".cv3." + ls + ".0.0.conv", x, d1, ACT_SILU);
+    cv(p + ".cv3." + ls + ".0.1.conv", d1, e1, 1, ACT_SILU);
+    dw(p + ".cv3." + ls + ".1.0.conv", e1, d2, ACT_SILU);
+    cv(p + ".cv3." + ls + ".1.1.conv", d2, e2, 1, ACT_SILU);
+    cv(p + ".cv3." + ls + ".2", e2, P.head[l].slice(64, nc_), 1, ACT_NONE);
+    if (nk > 0) {
+      TView k1 = P.alloc(lv, c4, T), k2 = P.alloc(lv, c4, T);
+      cv(p + ".cv4." + ls + ".0.conv", x, k1, 1, ACT_SILU);
+      cv(p + ".cv4." + ls + ".1.conv", k1, k2, 1, ACT_SILU);
+      cv(p + ".cv4." + ls + ".2", k2, P.head[l].slice(64 + nc_, nk), 1, ACT_NONE);
+    }
+  }
+
+  // ---- anchors -----------------------------------------------------------------------------------------------------------
+  P.anchor_off.assign(n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    int a = 0;
+    for (int l = 3; l < 6; ++l) a += P.L[l]->h[i] * P.L[l]->w[i];
+    P.anchor_off[i + 1] = P.anchor_off[i] + a;
+  }
+  P.total_anchors = P.anchor_off[n];
+  P.d_anchor_off.alloc(sizeof(int) * (n + 1));
+  FFP_HIP(hipMemcpyAsync(P.d_anchor_off.p, P.anchor_off.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, st_));
+  FFP_HIP(hipStreamSynchronize(st_));
+  P.d_boxes.alloc(sizeof(float4) * (size_t)P.total_anchors);
+  P.d_scores.alloc(sizeof(float) * (size_t)P.total_anchors);
+  P.d_classes.alloc(sizeof(int) * (size_t)P.total_anchors);
+  P.d_cand.alloc(sizeof(int) * (size_t)P.total_anchors);
+  P.d_cscore.alloc(sizeof(float) * (size_t)P.total_anchors);
+  P.d_lb.alloc(sizeof(LetterboxImg) * n);
+  P.d_imgs.alloc(sizeof(DetImg) * n);
+}
+
+std::vector<TileGeom> DetEngine::geometry(int H, int W, const int32_t* tiles, int n_tiles, int imgsz) const {
+  FFP_CHECK(H > 0 && W > 0 && n_tiles > 0 && tiles, FFP_ERR_ARG, "empty frame or tile list");
+  std::vector<TileGeom> g(n_tiles);
+  for (int i = 0; i < n_tiles; ++i) {
+    const int x0 = tiles[4 * i], y0 = tiles[4 * i + 1], x1 = tiles[4 * i + 2], y1 = tiles[4 * i + 3];
+    FFP_CHECK(x0 >= 0 && y0 >= 0 && x1 <= W && y1 <= H && x1 > x0 && y1 > y0, FFP_ERR_ARG, "tile %d [%d,%d,%d,%d] outside %dx%d frame",
+              i, x0, y0, x1, y1, W, H);
+    const int sw = x1 - x0, sh = y1 - y0;
+    int sz = imgsz;
+    if (sz <= 0) sz = (std::max(tiles[2] - tiles[0], tiles[3] - tiles[1]) + 31) / 32 * 32;
+    FFP_CHECK(sz % 32 == 0 && sz >= 32 && sz <= 4096, FFP_ERR_ARG, "imgsz %d must be a multiple of 32 in [32,4096]", sz);
+    int32_t lg[6];
+    letterbox_geometry(sh, sw, sz, lg);
+    TileGeom& t = g[i];
+    t.lb.x0 = x0; t.lb.y0 = y0; t.lb.sw = sw; t.lb.sh = sh;
+    t.lb.new_w = lg[0]; t.lb.new_h = lg[1]; t.lb.top = lg[2]; t.lb.left = lg[4];
+    t.lb.net_h = lg[1] + lg[2] + lg[3]; t.lb.net_w = lg[0] + lg[4] + lg[5];
+    FFP_CHECK(t.lb.net_h % 32 == 0 && t.lb.net_w % 32 == 0, FFP_ERR_STATE, "letterboxed size %dx%d not a multiple of 32", t.lb.net_w, t.lb.net_h);
+    // ultralytics scale_boxes: gain = min(h1/h0, w1/w0); pad = round((w1 - w0*gain)/2 - 0.1), ...
+    const double gain = std::min((double)t.lb.net_h / sh, (double)t.lb.net_w / sw);
+    t.di.gain = (float)gain;
+    t.di.pad_x = (float)std::nearbyint((t.lb.net_w - sw * gain) / 2 - 0.1);
+    t.di.pad_y = (float)std::nearbyint((t.lb.net_h - sh * gain) / 2 - 0.1);
+    t.di.sw = sw; t.di.sh = sh; t.di.x0 = x0; t.di.y0 = y0;
+  }
+  return g;
+}
+
+DetPlan* DetEngine::plan_for(const std::vector<TileGeom>& g) {
+  std::vector<int> key;
+  key.reserve(g.size() * 2);
+  for (const TileGeom& t : g) { key.push_back(t.lb.net_h); key.push_back(t.lb.net_w); }
+  auto it = plans_.find(key);
+  if (it == plans_.end()) {
+    if (plans_.size() >= 8) plans_.clear();     // bound the cache; plans are cheap to rebuild
+    std::unique_ptr<DetPlan> p(new DetPlan());
+    std::vector<int> hs, ws;
+    for (const TileGeom& t : g) { hs.push_back(t.lb.net_h); ws.push_back(t.lb.net_w); }
+    build_plan(*p, hs, ws);
+    it = plans_.emplace(key, std::move(p)).first;
+  }
+  return it->second.get();
+}
+
+DetPlan* DetEngine::prepare(const uint8_t* d_frame, int H, int W, int chan_order, const int32_t* tiles, int n_tiles, int imgsz) {
+  FFP_HIP(hipSetDevice(device_));
+  geom_last_ = geometry(H, W, tiles, n_tiles, imgsz);
+  DetPlan* P = plan_for(geom_last_);
+  std::vector<LetterboxImg> lb(n_tiles);
+  std::vector<DetImg> di(n_tiles);
+  for (int i = 0; i < n_tiles; ++i) { lb[i] = geom_last_[i].lb; di[i] = geom_last_[i].di; }
+  FFP_HIP(hipMemcpyAsync(P->d_lb.p, lb.data(), sizeof(LetterboxImg) * n_tiles, hipMemcpyHostToDevice, st_));
+  FFP_HIP(hipMemcpyAsync(P->d_imgs.p, di.data(), sizeof(DetImg) * n_tiles, hipMemcpyHostToDevice, st_));
+  FFP_HIP(hipStreamSynchronize(st_));   // lb/di are stack vectors
+  FFP_HIP(hipEventRecord(ev_[0], st_));
+  launch_letterbox(d_frame, H, W, chan_order == FFP_CHAN_AS_BGR ? 1 : 0, P->d_lb, P->input, st_);
+  FFP_HIP(hipEventRecord(ev_[1], st_));
+  if (prof.enabled) prof.begin();
+  P->execute(st_, &prof);
+  FFP_HIP(hipEventRecord(ev_[2], st_));
+  last_conv_flops = P->conv_flops;
+  last_conv_launches = P->conv_launches;
+  return P;
+}
+
+static DecodeArgs decode_args(const DetPlan& P, int nc, int nkpt) {
+  DecodeArgs a{};
+  for (int l = 0; l < 3; ++l) {
+    a.head[l] = (const float*)P.head[l].ptr;
+    a.tab[l] = P.L[3 + l]->d_tab.as<int4>();
+  }
+  a.head_cs = P.head[0].cs; a.nc = nc; a.nkpt = nkpt; a.n_img = P.L[0]->n;
+  a.anchor_off = P.d_anchor_off.as<int>(); a.total_anchors = P.total_anchors;
+  return a;
+}
+
+void DetEngine::infer_tiles_dev(const uint8_t* d_frame, int H, int W, int chan_order, const int32_t* tiles, int n_tiles, int imgsz,
+                                float conf, float iou, int max_det, int round_boxes, float* d_out_dets, int32_t* d_out_counts) {
+  FFP_CHECK(max_det >= 1 && max_det <= 1024, FFP_ERR_ARG, "max_det %d outside [1,1024]", max_det);
+  DetPlan* P = prepare(d_frame, H, W, chan_order, tiles, n_tiles, imgsz);
+  const DecodeArgs a = decode_args(*P, nc_, nkpt_);
+  launch_decode(a, conf, P->d_boxes.as<float4>(), P->d_scores.as<float>(), P->d_classes.as<int>(), st_);
+  launch_nms(a, P->d_boxes.as<float4>(), P->d_scores.as<float>(), P->d_classes.as<int>(), P->d_cand.as<int>(),
+             P->d_cscore.as<float>(), P->d_imgs.as<DetImg>(), iou, max_det, round_boxes, det_stride(), d_out_dets, d_out_counts, st_);
+  FFP_HIP(hipEventRecord(ev_[3], st_));
+  FFP_HIP(hipStreamSynchronize(st_));
+  if (prof.enabled) prof.collect();
+  FFP_HIP(hipEventElapsedTime(&last_ms[1], ev_[0], ev_[1]));
+  FFP_HIP(hipEventElapsedTime(&last_ms[2], ev_[1], ev_[2]));
+  FFP_HIP(hipEventElapsedTime(&last_ms[3], ev_[2], ev_[3]));
+  FFP_HIP(hipEventElapsedTime(&last_ms[0], ev_[0], ev_[3]));
+  last_ms[4] = 0.f;
+}
+
+void DetEngine::forward_raw(const uint8_t* d_frame, int H, int W, int chan_order, const int32_t* tiles, int n_tiles, int imgsz,
+                            float* out_raw, size_t out_cap, int32_t* out_anchor_counts) {
+  DetPlan* P = prepare(d_frame, H, W, chan_order, tiles, n_tiles, imgsz);
+  const DecodeArgs a = decode_args(*P, nc_, nkpt_);
+  const int no = 4 + nc_ + 3 * nkpt_;
+  std::vector<long long> off(n_tiles);
+  long long tot = 0;
+  for (int i = 0; i < n_tiles; ++i) {
+    off[i] = tot;
+    const int A = P->anchor_off[i + 1] - P->anchor_off[i];
+    out_anchor_counts[i] = A;
+    tot += (long long)no * A;
+  }
+  FFP_CHECK((size_t)tot <= out_cap, FFP_ERR_ARG, "forward_raw: output needs %lld floats, capacity %zu", tot, out_cap);
+  DevBuf d_off(sizeof(long long) * n_tiles), d_out(sizeof(float) * (size_t)tot);
+  FFP_HIP(hipMemcpyAsync(d_off.p, off.data(), sizeof(long long) * n_tiles, hipMemcpyHostToDevice, st_));
+  launch_decode_raw(a, d_out.as<float>(), d_off.as<long long>(), st_);
+  FFP_HIP(hipMemcpyAsync(out_raw, d_out.p, sizeof(float) * (size_t)tot, hipMemcpyDeviceToHost, st_));
+  FFP_HIP(hipStreamSynchronize(st_));
+  if (prof.enabled) prof.collect();
+}
+
+void DetEngine::truncate_shift_dev(float* d_dets, const int32_t* d_counts, int n_tiles, int max_det, int H, int W) {
+  FFP_CHECK((int)geom_last_.size() == n_tiles, FFP_ERR_STATE, "truncate_shift: no matching infer call");
+  DetPlan* P = plan_for(geom_last_);
+  launch_truncate_shift(d_dets, d_counts, P->d_imgs.as<DetImg>(), n_tiles, max_det, det_stride(), nkpt_, H, W, st_);
+}
+
+void DetEngine::merge_dev(const float* d_dets, const int32_t* d_counts, int n_slices, int max_det, int type, int metric, double thr,
+                          int class_agnostic, float* d_out, int32_t* d_out_src, int cap, int32_t* d_out_n) {
+  FFP_HIP(hipSetDevice(device_));
+  const int stride = det_stride();
+  const int n_max = n_slices * max_det;
+  scratch_rows.ensure(sizeof(float) * (size_t)n_max * stride);
+  scratch_n.ensure(sizeof(int));
+  scratch_prefix.ensure(sizeof(int) * (n_slices + 1));
+  FFP_HIP(hipEventRecord(ev_[4], st_));
+  launch_compact_rows(d_dets, d_counts, n_slices, max_det, stride, scratch_rows.as<float>(), scratch_n.as<int>(),
+                      scratch_prefix.as<int>(), st_);
+  run_merge(merge_work, scratch_rows.as<float>(), scratch_n.as<int>(), n_max, stride, type, metric, thr, class_agnostic, d_out,
+            d_out_src, d_out_n, cap, st_);
+  FFP_HIP(hipEventRecord(ev_[5], st_));
+  FFP_HIP(hipStreamSynchronize(st_));
+  FFP_HIP(hipEventElapsedTime(&last_ms[4], ev_[4], ev_[5]));
+}
+
+}  // namespace ffp

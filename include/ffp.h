@@ -1,0 +1,203 @@
+/*
+ * ffp.h — C-ABI of the MI355X-native sliced-inference face pipeline (libffp.so).
+ *
+ * Drop-in boundary for the hot path  SAHI slice -> YOLO11-pose detect -> per-slice NMS -> SAHI merge ->
+ * Real-ESRGAN x4 on crops.  The reference has no native code and no FFI: it reaches this arithmetic through four
+ * pip packages called from Python.  Each entry point below names the reference interface it replaces (paths are
+ * relative to /root/reference).  Binding shown in INTEGRATION.md (ctypes).
+ *
+ * Conventions: return 0 (FFP_OK) on success, a positive FFP_ERR_* code otherwise; ffp_last_error() returns a
+ * thread-local message.  Callers own every input and output buffer; outputs are caller-allocated.  A handle is
+ * bound to one HIP device and one internal stream and is NOT thread-safe (the reference wrapper is not re-entrant
+ * either: utils/yolo_wrapper.py keeps per-call state in self._original_predictions).
+ * No function here falls back to a CPU implementation: without a gfx950 device every compute call fails.
+ */
+#ifndef FFP_H
+#define FFP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFP_OK 0
+#define FFP_ERR_ARG 1      /* bad argument */
+#define FFP_ERR_HIP 2      /* HIP runtime / no device */
+#define FFP_ERR_WEIGHTS 3  /* malformed FFPW container or missing tensor */
+#define FFP_ERR_NOMEM 4
+#define FFP_ERR_STATE 5
+
+/* arithmetic type of the convolution path */
+#define FFP_PREC_F32 0 /* fp32 activations, v_mfma_f32_32x32x2_f32 (exact-f32 parity mode) */
+#define FFP_PREC_F16 1 /* fp16 activations, v_mfma_f32_32x32x16_f16, fp32 accumulate */
+
+/* how a caller's HxWx3 uint8 array maps to network channels.
+ * AS_BGR reproduces Ultralytics' ndarray path (network channel 0 = array[...,2]) which is what the reference gets,
+ * also when SAHI hands it an RGB array (docs sahi/predict.py:103-106 + utils/yolo_wrapper.py:74-80). */
+#define FFP_CHAN_AS_BGR 0
+#define FFP_CHAN_AS_RGB 1
+
+/* SAHI post-process selectors (docs sahi/predict.py:44-49,150-153) */
+#define FFP_PP_NMS 0
+#define FFP_PP_GREEDYNMM 1
+#define FFP_METRIC_IOU 0
+#define FFP_METRIC_IOS 1
+
+/* floats per detection row: x1,y1,x2,y2,score,class, then nkpt*(x,y,conf) */
+#define FFP_DET_STRIDE(nkpt) (6 + 3 * (nkpt))
+
+typedef struct ffp_det ffp_det;
+typedef struct ffp_sr ffp_sr;
+
+const char* ffp_last_error(void);
+int ffp_version(void);
+/* number of visible HIP devices (0 and FFP_OK when none) */
+int ffp_device_count(int* out_n);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * host logic
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* sahi.slicing.get_slice_bboxes (called through slice_image at docs sahi/predict.py:229-238).
+ * Writes up to cap [xmin,ymin,xmax,ymax] rows, row-major over the grid; *out_n = number of slices (may exceed cap,
+ * in which case only cap rows were written). */
+int ffp_slice_bboxes(int image_h, int image_w, int slice_h, int slice_w, float overlap_h_ratio, float overlap_w_ratio,
+                     int32_t* out_xyxy, int cap, int32_t* out_n);
+
+/* Ultralytics LetterBox(new_shape=imgsz, auto=True, stride=32) geometry for one (h,w) source:
+ * out[6] = {new_w, new_h, top, bottom, left, right}.  (inside YOLO.predict, utils/yolo_wrapper.py:74-80) */
+int ffp_letterbox_geometry(int h, int w, int imgsz, int32_t* out6);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * detector — replaces ultralytics.YOLO(model_path) + .predict(...) behind
+ * YOLOv11PoseDetectionModel.load_model / perform_inference (utils/yolo_wrapper.py:47-56, 63-82)
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* weights: FFPW container (see weights_io.py) holding the fused conv tensors of YOLO11{n,s}-pose.
+ * arch: 'n' or 's'.  nc classes, nkpt keypoints of 3 values.  precision: FFP_PREC_*. */
+int ffp_det_create(const void* weights, size_t nbytes, int arch, int nc, int nkpt, int device, int precision,
+                   ffp_det** out);
+void ffp_det_destroy(ffp_det* d);
+
+/* One batched `predict` over n_tiles crops of one frame (each crop = one `model.predict(source=slice)` call of the
+ * reference; the crop [0,0,W,H] is the "standard" full-frame prediction of docs sahi/predict.py:301-314).
+ * frame_hwc: HxWx3 uint8 (host).  tiles_xyxy: n_tiles x [x0,y0,x1,y1] in frame pixels.
+ * Each crop is letterboxed to imgsz (imgsz <= 0: native — the longer crop side rounded up to a multiple of 32),
+ * run through the network, decoded, conf-filtered (score > conf), NMS'ed (IoU > iou suppressed, at most max_det
+ * kept, score descending) and mapped back to crop pixels (scale_boxes / scale_coords, clipped to the crop).
+ * out_dets: [n_tiles][max_det][FFP_DET_STRIDE(nkpt)] float32, crop-local coordinates, NOT truncated.
+ * out_counts: [n_tiles].  round_boxes != 0 applies the `.round()` of older Ultralytics PosePredictor. */
+int ffp_det_infer_tiles(ffp_det* d, const uint8_t* frame_hwc, int H, int W, int chan_order,
+                        const int32_t* tiles_xyxy, int n_tiles, int imgsz, float conf, float iou, int max_det,
+                        int round_boxes, float* out_dets, int32_t* out_counts);
+
+/* Same, with the frame already resident in device memory and outputs written to device memory
+ * (all three pointers are device pointers on the handle's device).  Work is enqueued on the handle's stream and
+ * the call returns after the stream has drained. */
+int ffp_det_infer_tiles_dev(ffp_det* d, const uint8_t* d_frame_hwc, int H, int W, int chan_order,
+                            const int32_t* tiles_xyxy_host, int n_tiles, int imgsz, float conf, float iou,
+                            int max_det, int round_boxes, float* d_out_dets, int32_t* d_out_counts);
+
+/* Raw network output for parity tests: for each tile the inference-mode Pose head output (4+nc+3*nkpt, A_t)
+ * float32 = [cx,cy,w,h, class sigmoid.., kpt x,y,sigmoid(v)..] in net-input pixels, written back to back.
+ * out_anchor_counts[n_tiles] receives A_t.  out_cap = capacity of out_raw in floats. */
+int ffp_det_forward_raw(ffp_det* d, const uint8_t* frame_hwc, int H, int W, int chan_order,
+                        const int32_t* tiles_xyxy, int n_tiles, int imgsz, float* out_raw, size_t out_cap,
+                        int32_t* out_anchor_counts);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * SAHI merge — replaces sahi.postprocess.combine.{NMSPostprocess,GreedyNMMPostprocess}.__call__
+ * (constructed at docs sahi/predict.py:254-259, invoked :297,319)
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* dets: n rows of `stride` floats (host), first six = x1,y1,x2,y2,score,class (full-frame coords, as SAHI holds
+ * them: ints stored as floats).  out: up to n rows of `stride` floats, in SAHI's output order; for GREEDYNMM the box
+ * is the union, the score the max, and the remaining columns come from the higher-scored source row.
+ * out_src_index[k] = index of that source row.  Runs on `device`. */
+int ffp_merge(int device, const float* dets, int n, int stride, int type, int metric, double thr, int class_agnostic,
+              float* out, int32_t* out_src_index, int32_t* out_n);
+
+/* Fused get_sliced_prediction (docs sahi/predict.py:142-345) for a host frame: slice grid -> batched predict ->
+ * int-truncate + shift (utils/yolo_wrapper.py:137-162, docs sahi/prediction.py:94-120) -> optional full-frame
+ * prediction when more than one slice -> merge when more than one box.  out rows as in ffp_merge. */
+int ffp_sliced_predict(ffp_det* d, const uint8_t* frame_hwc, int H, int W, int chan_order, int slice_h, int slice_w,
+                       float overlap_h_ratio, float overlap_w_ratio, int perform_standard_pred, int imgsz,
+                       float conf, float iou, int max_det, int round_boxes, int pp_type, int pp_metric, double pp_thr,
+                       int class_agnostic, float* out, int cap, int32_t* out_n);
+
+/* Device-resident variant used by bench.py / multi-GPU: frame and outputs are device pointers. rank/world shard the
+ * slice list contiguously (rank r takes slices [r*ceil(n/world), ...)); with world > 1 the call stops after the
+ * per-rank detections are written to d_local_dets/d_local_counts (global slice order, fixed cap max_det) so that the
+ * caller can all-gather them (RCCL) and finish with ffp_merge_dev. */
+int ffp_det_stage_dev(ffp_det* d, const uint8_t* d_frame_hwc, int H, int W, int chan_order, int slice_h, int slice_w,
+                      float overlap_h_ratio, float overlap_w_ratio, int perform_standard_pred, int imgsz, float conf,
+                      float iou, int max_det, int round_boxes, int rank, int world, float* d_local_dets,
+                      int32_t* d_local_counts, int32_t* out_n_local, int32_t* out_n_total);
+
+/* Merge of fixed-cap per-slice detections already on the device: d_dets [n_slices][max_det][stride] (full-frame,
+ * truncated+shifted), d_counts[n_slices].  d_out [cap][stride], d_out_n[1] device pointers. */
+int ffp_merge_dev(ffp_det* d, const float* d_dets, const int32_t* d_counts, int n_slices, int max_det, int type,
+                  int metric, double thr, int class_agnostic, float* d_out, int cap, int32_t* d_out_n);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * super-resolution — replaces basicsr RRDBNet + realesrgan.RealESRGANer behind FaceEnhancer
+ * (utils/enhancer.py:99-156 construction, :214 `self.upsampler.enhance(image, outscale=self.scale)`)
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* weights: FFPW container with RRDBNet tensors.  scale 4 (x4plus) or 2 (x2plus, pixel-unshuffle front).
+ * half != 0 -> FFP_PREC_F16 (the reference's GPU default, utils/enhancer.py:22), else fp32. */
+int ffp_sr_create(const void* weights, size_t nbytes, int scale, int num_block, int device, int half, ffp_sr** out);
+void ffp_sr_destroy(ffp_sr* s);
+
+/* RealESRGANer.enhance for one 3-channel uint8 BGR image (host). out_bgr: (scale*h) x (scale*w) x 3 uint8.
+ * tile <= 0: whole image in one pass; else tiles of `tile` px padded by tile_pad (clipped). */
+int ffp_sr_enhance(ffp_sr* s, const uint8_t* bgr_hwc, int h, int w, int tile, int tile_pad, int pre_pad,
+                   uint8_t* out_bgr);
+
+/* n independent images in one ragged batch (one launch per layer for all of them). */
+int ffp_sr_enhance_batch(ffp_sr* s, int n, const uint8_t* const* imgs, const int32_t* hs, const int32_t* ws, int tile,
+                         int tile_pad, int pre_pad, uint8_t* const* outs);
+
+/* Crops gathered on the device from a resident frame (utils/visualization.py:185-223 crop semantics: int box,
+ * clamped to the frame), enhanced, outputs packed back to back in d_out (device), offsets in out_offsets (host,
+ * n+1 entries, bytes). frame is BGR. boxes_xyxy: host int32 [n][4]. */
+int ffp_sr_enhance_crops_dev(ffp_sr* s, const uint8_t* d_frame_bgr, int H, int W, const int32_t* boxes_xyxy, int n,
+                             uint8_t* d_out, size_t out_cap, int64_t* out_offsets);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * single-operator entry points (layer-wise parity tests; host NHWC fp32 in/out, computed on `device` in `precision`)
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* y = act(conv2d(x, w) + b) [* s1 + res]; x: [n][h][w][cin] fp32 NHWC; w: OIHW fp32 (groups: 1 or cin==cout
+ * depthwise); k in {1,3}; stride in {1,2}; pad = k/2; act: 0 none, 1 SiLU, 2 LeakyReLU(0.2); up: nearest x2 of x
+ * before the conv (0/1); res: optional residual [n][ho][wo][cout] (NULL: none). y: [n][ho][wo][cout] fp32. */
+int ffp_op_conv2d(int device, int precision, const float* x, int n, int h, int w, int cin, const float* wt,
+                  const float* bias, int cout, int k, int stride, int groups, int act, int up, const float* res,
+                  float res_scale, float* y);
+
+/* timing hooks for bench.py: HIP-event milliseconds of the last call on the handle, by stage
+ * stage: 0 total, 1 preprocess, 2 network, 3 decode+nms, 4 merge */
+int ffp_det_last_ms(ffp_det* d, int stage, float* out_ms);
+int ffp_sr_last_ms(ffp_sr* s, float* out_ms);
+
+/* algorithmic conv FLOPs (2*MAC) of the last call, its number of convolution launches, and (profiling enabled) the
+ * HIP-event time spent in convolution kernels */
+int ffp_det_last_conv_stats(ffp_det* d, double* out_flops, float* out_ms, int32_t* out_launches);
+int ffp_sr_last_conv_stats(ffp_sr* s, double* out_flops, float* out_ms, int32_t* out_launches);
+
+/* Per-launch HIP-event profiling of the convolution kernels on the handle's stream. While enabled every conv launch
+ * of a call is bracketed by two events; afterwards the table lists, per kernel variant ("f16_k3s1_narrow1", ...),
+ * the algorithmic FLOPs, the summed event time and the launch count of the LAST call. */
+int ffp_det_set_profile(ffp_det* d, int enable);
+int ffp_det_profile_count(ffp_det* d, int32_t* out_n);
+int ffp_det_profile_get(ffp_det* d, int i, char* name, int name_cap, double* out_flops, float* out_ms, int32_t* out_launches);
+int ffp_sr_set_profile(ffp_sr* s, int enable);
+int ffp_sr_profile_count(ffp_sr* s, int32_t* out_n);
+int ffp_sr_profile_get(ffp_sr* s, int i, char* name, int name_cap, double* out_flops, float* out_ms, int32_t* out_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFP_H */

@@ -1,0 +1,97 @@
+"""GPU parity of the MFMA convolution kernels (through the C-ABI ffp_op_conv2d) against a plain PyTorch fp32
+reference of the same op. fp32 mode: exact-f32 MFMA, tolerance = summation-order noise. fp16 mode: operands rounded
+to fp16 on both sides, fp32 accumulate, output rounded to fp16 (tolerance stated per assert)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ACTS = {0: lambda t: t, 1: F.silu, 2: lambda t: F.leaky_relu(t, 0.2)}
+
+
+def ref_conv(x, w, b, stride, groups, act, up, res, res_scale, half):
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    wt = torch.from_numpy(w)
+    if half:
+        xt = xt.half().float()
+        wt = wt.half().float()
+    if up:
+        xt = F.interpolate(xt, scale_factor=2, mode="nearest")
+    y = F.conv2d(xt, wt, torch.from_numpy(b), stride=stride, padding=w.shape[2] // 2, groups=groups)
+    y = ACTS[act](y)
+    if res is not None:
+        r = torch.from_numpy(res).permute(0, 3, 1, 2)
+        if half:
+            r = r.half().float()
+        y = y * res_scale + r
+    return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+CASES = [
+    # (n, h, w, cin, cout, k, stride, act, up, res)
+    (2, 16, 16, 64, 128, 1, 1, 1, 0, False),
+    (1, 20, 24, 96, 32, 1, 1, 0, 0, True),
+    (3, 9, 16, 512, 512, 1, 1, 1, 0, False),
+    (1, 16, 16, 48, 64, 1, 1, 1, 0, False),
+    (2, 32, 32, 32, 64, 3, 1, 1, 0, True),
+    (1, 18, 37, 64, 32, 3, 1, 2, 0, False),
+    (1, 13, 11, 192, 64, 3, 1, 0, 0, True),
+    (1, 24, 24, 160, 32, 3, 1, 2, 0, False),
+    (2, 32, 32, 4, 32, 3, 2, 1, 0, False),
+    (1, 64, 48, 64, 128, 3, 2, 1, 0, False),
+    (1, 16, 16, 256, 256, 3, 2, 1, 0, False),
+    (1, 12, 10, 64, 64, 3, 1, 2, 1, False),
+    (1, 16, 16, 64, 3, 3, 1, 0, 0, False),
+    (1, 16, 16, 128, 1, 1, 1, 0, 0, False),
+    (1, 16, 16, 32, 15, 1, 1, 0, 0, False),
+    (2, 8, 8, 16, 16, 3, 1, 1, 0, True),
+    (1, 16, 16, 8, 16, 3, 1, 1, 0, False),
+    (1, 8, 8, 1024, 512, 1, 1, 1, 0, False),
+    (1, 16, 16, 768, 256, 1, 1, 1, 0, False),
+]
+
+
+@pytest.mark.parametrize("half", [False, True], ids=["f32", "f16"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_%dx%d_c%d-%d_k%ds%d_a%d_u%d_r%d" % c)
+def test_conv_dense(gpu_lib, case, half):
+    n, h, w, cin, cout, k, stride, act, up, has_res = case
+    if half and cin % 8:
+        pytest.skip("fp16 activations are addressed in 8-channel vectors")
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, cin, k, k), dtype=np.float32) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout, dtype=np.float32) * 0.1
+    hi, wi = (h * 2, w * 2) if up else (h, w)
+    ho, wo = (hi + 2 * (k // 2) - k) // stride + 1, (wi + 2 * (k // 2) - k) // stride + 1
+    res = rng.standard_normal((n, ho, wo, cout), dtype=np.float32) if has_res else None
+    y = gpu_lib.op_conv2d(x, wt, b, stride=stride, act=act, up=bool(up), res=res, res_scale=0.2 if has_res else 1.0,
+                          precision=gpu_lib.PREC_F16 if half else gpu_lib.PREC_F32)
+    ref = ref_conv(x, wt, b, stride, 1, act, up, res, 0.2, half)
+    assert y.shape == ref.shape
+    if half:
+        # operands identical (fp16-rounded), fp32 accumulate; the only difference is the final rounding to fp16
+        np.testing.assert_allclose(y, ref, rtol=2e-3, atol=2e-3)
+    else:
+        np.testing.assert_allclose(y, ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("half", [False, True], ids=["f32", "f16"])
+@pytest.mark.parametrize("c,h,w,act,has_res", [(128, 16, 16, 1, False), (256, 9, 16, 0, True), (64, 33, 17, 1, False)])
+def test_conv_depthwise(gpu_lib, c, h, w, act, has_res, half):
+    rng = np.random.default_rng(c + h)
+    x = rng.standard_normal((2, h, w, c), dtype=np.float32)
+    wt = rng.standard_normal((c, 1, 3, 3), dtype=np.float32) / 3
+    b = rng.standard_normal(c, dtype=np.float32) * 0.1
+    res = rng.standard_normal((2, h, w, c), dtype=np.float32) if has_res else None
+    y = gpu_lib.op_conv2d(x, wt, b, groups=c, act=act, res=res, precision=gpu_lib.PREC_F16 if half else gpu_lib.PREC_F32)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    if half:
+        xt = xt.half().float()
+    r = ACTS[act](F.conv2d(xt, torch.from_numpy(wt), torch.from_numpy(b), padding=1, groups=c))
+    if has_res:
+        rr = torch.from_numpy(res).permute(0, 3, 1, 2)
+        r = r + (rr.half().float() if half else rr)
+    ref = r.permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(y, ref, rtol=2e-3 if half else 2e-5, atol=2e-3 if half else 2e-5)
