@@ -1,0 +1,94 @@
+"""GPU parity of the detector path (C-ABI ffp_det_*) against the CPU oracle on the same seeded inputs.
+
+Tolerances (north_star): box IoU >= 0.999 and identical class ids vs the CPU path — asserted for the fp32 (exact-f32
+MFMA) mode on float, pre-truncation boxes. The fp16 mode is a speed mode: asserted at IoU >= 0.90 / score 2e-2."""
+import numpy as np
+import pytest
+import torch
+
+from util import iou_xyxy, match_by_iou
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["n", "s"])
+def models(request, gpu_lib):
+    from ffp_amd import synth
+    from oracle.yolo11_ref import Yolo11PoseRef
+    sc = request.param
+    W = synth.yolo11_pose_weights(sc)
+    return sc, Yolo11PoseRef(W, sc), gpu_lib.Detector(W, arch=sc, precision=gpu_lib.PREC_F32), W
+
+
+@pytest.fixture(scope="module")
+def frame():
+    from ffp_amd import synth
+    return synth.synthetic_frame(480, 640, seed=7)
+
+
+TILES = [(0, 0, 256, 256), (100, 50, 356, 306), (0, 0, 640, 480), (20, 30, 320, 230), (384, 224, 640, 480)]
+
+
+def test_forward_raw_matches_oracle(models, frame):
+    from oracle import ultra_post
+    sc, ref, det, _ = models
+    outs = det.forward_raw(frame, TILES, 256)
+    for t, o in zip(TILES, outs):
+        crop = frame[t[1]:t[3], t[0]:t[2]]
+        r = ref.forward(ultra_post.preprocess(crop, 256))[0].numpy()
+        assert o.shape == r.shape, (t, o.shape, r.shape)
+        np.testing.assert_allclose(o[4], r[4], atol=2e-4, rtol=0)            # class sigmoid
+        np.testing.assert_allclose(o[:4], r[:4], atol=2e-2, rtol=0)          # cx,cy,w,h in net pixels
+        np.testing.assert_allclose(o[5:], r[5:], atol=2e-2, rtol=1e-4)       # keypoints
+
+
+@pytest.mark.parametrize("conf", [0.5, 0.05])
+def test_infer_tiles_matches_oracle(models, frame, conf):
+    from oracle import ultra_post
+    sc, ref, det, _ = models
+    res = det.infer_tiles(frame, TILES, 256, conf, 0.7, 300)
+    total = 0
+    for t, d in zip(TILES, res):
+        crop = frame[t[1]:t[3], t[0]:t[2]]
+        r = ultra_post.predict(ref, crop, 256, conf, 0.7, 300)
+        assert d.shape[0] == len(r), (t, d.shape[0], len(r))
+        if len(r) == 0:
+            continue
+        total += len(r)
+        # same order except for near-ties in score: match by IoU
+        m = match_by_iou(r.xyxy, d[:, :4])
+        ious = np.array([x[2] for x in m])
+        assert ious.min() >= 0.999, (t, ious.min())
+        j = np.array([x[1] for x in m])
+        np.testing.assert_allclose(d[j, 4], r.conf, atol=2e-4)
+        assert np.array_equal(d[j, 5].astype(int), r.cls.astype(int))
+        np.testing.assert_allclose(d[j, 6:].reshape(-1, 5, 3), r.kpts, atol=5e-2, rtol=1e-4)
+        # exact-int agreement of the wrapper's truncation (informational floor: 98 %)
+        same = (d[j, :4].astype(int) == r.xyxy.astype(int)).all(1).mean()
+        assert same >= 0.98, same
+    assert total > 0
+
+
+def test_fp16_mode_close(models, frame, gpu_lib):
+    from oracle import ultra_post
+    sc, ref, _, W = models
+    det16 = gpu_lib.Detector(W, arch=sc, precision=gpu_lib.PREC_F16)
+    outs = det16.forward_raw(frame, TILES[:2], 256)
+    for t, o in zip(TILES[:2], outs):
+        crop = frame[t[1]:t[3], t[0]:t[2]]
+        r = ref.forward(ultra_post.preprocess(crop, 256))[0].numpy()
+        np.testing.assert_allclose(o[4], r[4], atol=3e-2)
+        hot = r[4] > 0.25
+        if hot.any():
+            a = np.stack([r[0] - r[2] / 2, r[1] - r[3] / 2, r[0] + r[2] / 2, r[1] + r[3] / 2], 1)[hot]
+            b = np.stack([o[0] - o[2] / 2, o[1] - o[3] / 2, o[0] + o[2] / 2, o[1] + o[3] / 2], 1)[hot]
+            assert np.median(iou_xyxy(a, b)) >= 0.97
+
+
+def test_letterbox_geometry_kat(gpu_lib):
+    # SURVEY.md §8c KAT: 3840x2160 @1024 -> 1024x576, no pad; @512 -> 512x288
+    assert gpu_lib.letterbox_geometry(2160, 3840, 1024) == (1024, 576, 0, 0, 0, 0)
+    assert gpu_lib.letterbox_geometry(2160, 3840, 512) == (512, 288, 0, 0, 0, 0)
+    from oracle import ultra_post
+    for (h, w, s) in [(200, 300, 256), (480, 640, 256), (333, 777, 640), (512, 512, 1024), (1080, 1920, 640)]:
+        assert gpu_lib.letterbox_geometry(h, w, s) == ultra_post.letterbox_geometry(h, w, s)

@@ -1,0 +1,72 @@
+"""GPU parity of the fused sliced prediction (C-ABI ffp_sliced_predict) against the oracle's restatement of
+get_sliced_prediction + wrapper conversion, on a frame large enough for a 3x3 slice grid + the full-frame pass."""
+import numpy as np
+import pytest
+
+from util import iou_xyxy, match_by_iou
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(gpu_lib):
+    from ffp_amd import synth
+    from oracle.yolo11_ref import Yolo11PoseRef
+    W = synth.yolo11_pose_weights("n")
+    frame = synth.synthetic_frame(600, 700, seed=11)
+    return Yolo11PoseRef(W, "n"), gpu_lib.Detector(W, arch="n", precision=gpu_lib.PREC_F32), frame
+
+
+@pytest.mark.parametrize("ptype,metric,agn", [("GREEDYNMM", "IOS", False), ("NMS", "IOS", True), ("NMS", "IOU", False)])
+def test_sliced_predict_matches_oracle(setup, ptype, metric, agn):
+    from oracle import sahi_ref, ultra_post
+    ref, det, frame = setup
+    conf, imgsz, sl = 0.5, 256, 256
+    out = det.sliced_predict(frame, sl, sl, 0.2, 0.2, True, imgsz, conf, 0.7, 300, ptype, metric, 0.5, agn)
+    dets = sahi_ref.get_sliced_prediction(frame, lambda im: ultra_post.predict(ref, im, imgsz, conf, 0.7, 300), sl, sl, 0.2, 0.2, True,
+                                          ptype, metric, 0.5, agn)
+    rb = np.asarray([d.bbox for d in dets], np.float32).reshape(-1, 4)
+    assert abs(out.shape[0] - rb.shape[0]) <= max(1, rb.shape[0] // 50), (out.shape[0], rb.shape[0])
+    m = match_by_iou(rb, out[:, :4])
+    ious = np.array([x[2] for x in m])
+    # int-truncated boxes: a 1-px flip on a sub-1e-3 px float difference is possible but must be rare
+    assert (ious >= 0.999).mean() >= 0.97, (ious >= 0.999).mean()
+    exact = np.mean([np.array_equal(rb[i], out[j, :4]) for i, j, _ in m])
+    assert exact >= 0.97, exact
+    assert np.all(out[:, :4] == np.trunc(out[:, :4]))
+
+
+def test_sliced_equals_tilewise_composition(setup, gpu_lib):
+    """The fused call must equal: infer_tiles -> int truncate/shift on the host -> ffp_merge (bit exact)."""
+    ref, det, frame = setup
+    H, W = frame.shape[:2]
+    sl = gpu_lib.slice_bboxes(H, W, 256, 256, 0.2, 0.2)
+    tiles = [tuple(t) for t in sl] + [(0, 0, W, H)]
+    per = det.infer_tiles(frame, tiles, 256, 0.5, 0.7, 300)
+    rows = []
+    for t, d in zip(tiles, per):
+        d = d.copy()
+        b = np.trunc(d[:, :4])
+        b[:, 0] = np.maximum(b[:, 0], 0); b[:, 1] = np.maximum(b[:, 1], 0)
+        b[:, 2] = np.minimum(b[:, 2], W); b[:, 3] = np.minimum(b[:, 3], H)
+        d[:, 0] = b[:, 0] + t[0]; d[:, 1] = b[:, 1] + t[1]; d[:, 2] = b[:, 2] + t[0]; d[:, 3] = b[:, 3] + t[1]
+        d[:, 6::3] += t[0]; d[:, 7::3] += t[1]
+        rows.append(d)
+    rows = np.concatenate(rows, 0)
+    merged, _ = gpu_lib.merge(rows, "GREEDYNMM", "IOS", 0.5)
+    fused = det.sliced_predict(frame, 256, 256, 0.2, 0.2, True, 256, 0.5, 0.7, 300, "GREEDYNMM", "IOS", 0.5, False)
+    assert np.array_equal(merged, fused)
+
+
+def test_slice_grid_kats(gpu_lib):
+    # SURVEY.md Appendix C.1 known answers
+    b = gpu_lib.slice_bboxes(2160, 3840, 512, 512, 0.2, 0.2)
+    assert len(b) == 60
+    assert sorted(set(b[:, 0].tolist())) == [0, 410, 820, 1230, 1640, 2050, 2460, 2870, 3280, 3328]
+    assert sorted(set(b[:, 1].tolist())) == [0, 410, 820, 1230, 1640, 1648]
+    assert len(gpu_lib.slice_bboxes(2160, 3840, 640, 640, 0.2, 0.2)) == 32
+    assert len(gpu_lib.slice_bboxes(2160, 3840, 640, 640, 0.25, 0.25)) == 40
+    b = gpu_lib.slice_bboxes(4320, 7680, 640, 640, 0.25, 0.25)
+    assert len(b) == 144 and b[:, 0].max() == 7040 and b[:, 1].max() == 3680
+    assert len(gpu_lib.slice_bboxes(4320, 7680, 512, 512, 0.2, 0.2)) == 209
+    assert gpu_lib.slice_bboxes(300, 400, 512, 512, 0.2, 0.2).tolist() == [[0, 0, 400, 300]]
