@@ -48,6 +48,7 @@ _SIGS = {
                                       C.c_float, C.c_int, C.c_int, _p(C.c_float), _p(C.c_int32)]),
     "ffp_det_infer_tiles_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _p(C.c_int32), C.c_int, C.c_int, C.c_float,
                                           C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ffp_det_truncate_shift_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ffp_det_forward_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _p(C.c_int32), C.c_int, C.c_int, _p(C.c_float),
                                       C.c_size_t, _p(C.c_int32)]),
     "ffp_merge": (C.c_int, [C.c_int, _p(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _p(C.c_float), _p(C.c_int32),

@@ -127,6 +127,14 @@ int ffp_det_infer_tiles_dev(ffp_det* d, const uint8_t* d_frame, int H, int W, in
   FFP_API_END
 }
 
+int ffp_det_truncate_shift_dev(ffp_det* d, float* d_dets, const int32_t* d_counts, int n_tiles, int max_det, int full_h, int full_w) {
+  FFP_API_BEGIN
+  FFP_CHECK(d && d_dets && d_counts && n_tiles > 0, FFP_ERR_ARG, "bad argument");
+  d->eng.truncate_shift_dev(d_dets, d_counts, n_tiles, max_det, full_h, full_w);
+  FFP_HIP(hipStreamSynchronize(d->eng.stream()));
+  FFP_API_END
+}
+
 int ffp_det_forward_raw(ffp_det* d, const uint8_t* frame, int H, int W, int chan_order, const int32_t* tiles, int n_tiles, int imgsz,
                         float* out_raw, size_t out_cap, int32_t* out_anchor_counts) {
   FFP_API_BEGIN

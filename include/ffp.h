@@ -100,6 +100,13 @@ int ffp_det_infer_tiles_dev(ffp_det* d, const uint8_t* d_frame_hwc, int H, int W
                             const int32_t* tiles_xyxy_host, int n_tiles, int imgsz, float conf, float iou,
                             int max_det, int round_boxes, float* d_out_dets, int32_t* d_out_counts);
 
+/* The wrapper's conversion on the device, for the tiles of the handle's LAST infer call: boxes int-truncated and
+ * clipped like sahi's ObjectAnnotation, then boxes and keypoints shifted by the tile origin
+ * (utils/yolo_wrapper.py:137-162 + docs sahi/prediction.py:94-120). d_dets/d_counts as written by
+ * ffp_det_infer_tiles_dev. */
+int ffp_det_truncate_shift_dev(ffp_det* d, float* d_dets, const int32_t* d_counts, int n_tiles, int max_det, int full_h,
+                               int full_w);
+
 /* Raw network output for parity tests: for each tile the inference-mode Pose head output (4+nc+3*nkpt, A_t)
  * float32 = [cx,cy,w,h, class sigmoid.., kpt x,y,sigmoid(v)..] in net-input pixels, written back to back.
  * out_anchor_counts[n_tiles] receives A_t.  out_cap = capacity of out_raw in floats. */
