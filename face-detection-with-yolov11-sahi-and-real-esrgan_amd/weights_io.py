@@ -121,7 +121,7 @@ def from_ultralytics_state_dict(sd: Mapping[str, "np.ndarray"], bn_eps: float = 
     get = lambda k: (sd[k].detach().cpu().numpy() if hasattr(sd[k], "detach") else np.asarray(sd[k])).astype(np.float64)
     out: Dict[str, np.ndarray] = {}
     for k in sd:
-        if k.endswith(".conv.weight"):
+        if k.endswith(".conv.weight") and (k[: -len(".conv.weight")] + ".bn.weight") in sd:
             p = k[: -len(".conv.weight")]
             w = get(k)
             g, b = get(p + ".bn.weight"), get(p + ".bn.bias")
