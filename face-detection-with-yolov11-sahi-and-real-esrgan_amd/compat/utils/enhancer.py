@@ -1,0 +1,209 @@
+"""FaceEnhancer / RealESRGANer / RRDBNet with the reference's surface (utils/enhancer.py:21-478) over libffp.so.
+
+`enhance_image` keeps the reference's error convention — it never raises and returns `(image, success)` (:189-235).
+File I/O uses Pillow (cv2 is not a dependency of this build): BGR arrays in, BGR arrays out, JPEG quality honoured.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+from PIL import Image
+
+import ffp_amd  # noqa: F401
+from ffp_amd import _lib, synth, weights_io
+
+
+class RRDBNet:
+    """Architecture descriptor (basicsr.archs.rrdbnet_arch.RRDBNet signature); the network itself lives in libffp.so."""
+
+    def __init__(self, num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=23, num_grow_ch=32):
+        if (num_in_ch, num_out_ch, num_feat, num_grow_ch) != (3, 3, 64, 32):
+            raise ValueError("only RRDBNet(3, 3, num_feat=64, num_grow_ch=32) is built")
+        self.scale, self.num_block = scale, num_block
+
+
+class RealESRGANer:
+    """realesrgan.RealESRGANer(scale, model_path, dni_weight, model, tile, tile_pad, pre_pad, half, gpu_id) -> .enhance()."""
+
+    def __init__(self, scale, model_path, dni_weight=None, model=None, tile=0, tile_pad=10, pre_pad=0, half=False, device=None, gpu_id=None):
+        self.scale, self.tile_size, self.tile_pad, self.pre_pad, self.half = scale, tile, tile_pad, pre_pad, half
+        if model_path is None:
+            raise AttributeError("'NoneType' object has no attribute 'startswith'")   # what realesrgan 0.3.0 does
+        nb = model.num_block if model is not None else 23
+        if isinstance(model_path, dict):
+            W = model_path
+        elif str(model_path).startswith("synthetic:"):
+            W = synth.rrdbnet_weights(scale, nb)
+        elif str(model_path).startswith("https://"):
+            raise RuntimeError("weight download is not available offline; pass a local .pth / .ffpw")
+        elif str(model_path).endswith(".ffpw"):
+            W = weights_io.load(model_path)
+        else:
+            W = weights_io.load_esrgan_pth(model_path)
+        self._sr = _lib.Enhancer(W, scale, nb, device=gpu_id or 0, half=bool(half))
+
+    def enhance(self, img, outscale=None, alpha_upsampler="realesrgan"):
+        if img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
+            raise ValueError("this build enhances 3-channel uint8 BGR images (the face-crop path)")
+        if outscale is not None and float(outscale) != float(self.scale):
+            raise NotImplementedError("outscale != scale (Lanczos resize) is never used by the reference (utils/enhancer.py:214)")
+        return self._sr.enhance(np.ascontiguousarray(img), self.tile_size, self.tile_pad, self.pre_pad), "RGB"
+
+
+def _imread_bgr(path):
+    try:
+        return np.asarray(Image.open(path).convert("RGB"))[..., ::-1].copy()
+    except Exception:
+        return None
+
+
+def _imwrite_bgr(path, img, quality=95):
+    try:
+        ext = os.path.splitext(path)[1].lower()
+        pil = Image.fromarray(np.ascontiguousarray(img[..., ::-1]))
+        pil.save(path, quality=quality) if ext in (".jpg", ".jpeg") else pil.save(path)
+        return True
+    except Exception:
+        return False
+
+
+class FaceEnhancer:
+    def __init__(self, model_name="RealESRGAN_x4plus", model_path=None, scale=4, tile=400, half=True):
+        self.model_name, self.scale, self.tile, self.half, self.upsampler = model_name, scale, tile, half, None
+        self.device = self._check_device()
+        print(f"Using device: {self.device}")
+        try:
+            self._setup_model(model_name, model_path)
+        except Exception as e:
+            print(f" Failed to setup model: {e}")
+            raise
+
+    def _check_device(self):
+        if _lib.device_count() > 0:
+            return "cuda"
+        return "cpu"
+
+    def _find_model_path(self, model_name):
+        for p in (f"models/{model_name}.pth", f"./models/{model_name}.pth", f"../models/{model_name}.pth", f"weights/{model_name}.pth",
+                  f"./weights/{model_name}.pth", f"{model_name}.pth", f"./{model_name}.pth"):
+            if os.path.exists(p):
+                return os.path.abspath(p)
+        return None
+
+    def _setup_model(self, model_name, model_path):
+        if self.device == "cpu":
+            raise RuntimeError("no MI355X visible: this build has no CPU enhancement path")
+        if model_path is None:
+            model_path = self._find_model_path(model_name)
+        if "anime_6B" in model_name:
+            model = RRDBNet(3, 3, num_feat=64, num_block=6, num_grow_ch=32, scale=self.scale)
+        elif "x2" in model_name:
+            model = RRDBNet(3, 3, num_feat=64, num_block=23, num_grow_ch=32, scale=2)
+            self.scale = 2                                           # reference quirk kept (utils/enhancer.py:109-119)
+        else:
+            model = RRDBNet(3, 3, num_feat=64, num_block=23, num_grow_ch=32, scale=self.scale)
+        self.upsampler = RealESRGANer(scale=self.scale, model_path=model_path, dni_weight=None, model=model, tile=self.tile, tile_pad=10,
+                                      pre_pad=0, half=self.half, gpu_id=0)
+
+    def enhance_image(self, image):
+        if self.upsampler is None:
+            return image, False
+        try:
+            if isinstance(image, Image.Image):
+                image = np.asarray(image.convert("RGB"))[..., ::-1].copy()
+            if image is None or image.size == 0:
+                return image, False
+            h, w = image.shape[:2]
+            if h < 4 or w < 4:
+                print(f" Image too small ({w}x{h}), skipping enhancement")
+                return image, False
+            out, _ = self.upsampler.enhance(image, outscale=self.scale)
+            return out, True
+        except Exception as e:
+            print(f" Enhancement failed: {type(e).__name__}: {e}")
+            return image, False
+
+    def enhance_face_crop(self, crop_path, output_path, quality=95):
+        info = {"original_path": crop_path, "output_path": output_path, "original_size": None, "enhanced_size": None,
+                "scale_factor": self.scale, "success": False}
+        try:
+            if not os.path.exists(crop_path):
+                return False, info
+            img = _imread_bgr(crop_path)
+            if img is None:
+                return False, info
+            info["original_size"] = (img.shape[1], img.shape[0])
+            out, ok = self.enhance_image(img)
+            if not ok:
+                return False, info
+            info["enhanced_size"] = (out.shape[1], out.shape[0])
+            os.makedirs(os.path.dirname(output_path) or ".", exist_ok=True)
+            if not _imwrite_bgr(output_path, out, quality):
+                return False, info
+            info["success"] = True
+            return True, info
+        except Exception as e:
+            print(f" Error enhancing {os.path.basename(crop_path)}: {e}")
+            return False, info
+
+    def get_model_info(self):
+        return {"model_name": self.model_name, "scale": self.scale, "tile": self.tile, "half_precision": self.half, "device": self.device,
+                "is_loaded": self.upsampler is not None, "backend": f"libffp {_lib.lib().ffp_version()}", "cuda_available": self.device == "cuda"}
+
+
+def enhance_face_crops_batch(crops_dir, enhancer, prefix="enhanced", progress_callback=None):
+    results = {"enhanced_files": [], "failed_files": [], "enhancement_info": [],
+               "statistics": {"total_files": 0, "successful": 0, "failed": 0, "total_time": 0}}
+    if not os.path.exists(crops_dir):
+        return results
+    out_dir = os.path.join(os.path.dirname(crops_dir), f"{prefix}_enhanced")
+    os.makedirs(out_dir, exist_ok=True)
+    files = [f for f in os.listdir(crops_dir) if f.lower().endswith((".png", ".jpg", ".jpeg", ".bmp", ".tiff"))]
+    results["statistics"]["total_files"] = len(files)
+    t0 = time.time()
+    for i, f in enumerate(files, 1):
+        name, ext = os.path.splitext(f)
+        dst = os.path.join(out_dir, f"{prefix}_{name}{ext}")
+        if progress_callback:
+            try:
+                progress_callback(i, len(files), f)
+            except Exception:
+                pass
+        ok, info = False, None
+        for _attempt in range(2):                                    # reference retries once (utils/enhancer.py:362-377)
+            try:
+                ok, info = enhancer.enhance_face_crop(os.path.join(crops_dir, f), dst)
+                if ok:
+                    break
+            except Exception:
+                ok = False
+        if ok and info:
+            results["enhanced_files"].append(dst)
+            results["enhancement_info"].append(info)
+            results["statistics"]["successful"] += 1
+        else:
+            results["failed_files"].append(os.path.join(crops_dir, f))
+            results["statistics"]["failed"] += 1
+    results["statistics"]["total_time"] = time.time() - t0
+    return results
+
+
+def create_enhancement_summary(results, output_path):
+    st = results["statistics"]
+    with open(output_path, "w", encoding="utf-8") as fh:
+        fh.write("REAL-ESRGAN ENHANCEMENT SUMMARY\n" + "=" * 50 + "\n")
+        fh.write(f"Total files: {st['total_files']}\nSuccessful: {st['successful']}\nFailed: {st['failed']}\n")
+        if st["total_files"]:
+            fh.write(f"Success rate: {st['successful'] / st['total_files'] * 100:.1f}%\n")
+        fh.write(f"Total time: {st['total_time']:.2f} s\n\n")
+        for info in results["enhancement_info"]:
+            fh.write(f"{os.path.basename(info['original_path'])}: {info['original_size']} -> {info['enhanced_size']} (x{info['scale_factor']})\n")
+        for f in results["failed_files"]:
+            fh.write(f"FAILED: {os.path.basename(f)}\n")
+
+
+def get_available_models():
+    return {"RealESRGAN_x4plus": {"scale": 4, "num_block": 23}, "RealESRGAN_x2plus": {"scale": 2, "num_block": 23},
+            "RealESRGAN_x4plus_anime_6B": {"scale": 4, "num_block": 6}}
