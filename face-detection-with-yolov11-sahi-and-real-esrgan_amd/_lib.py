@@ -66,6 +66,8 @@ _SIGS = {
     "ffp_det_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "ffp_det_profile_count": (C.c_int, [C.c_void_p, _p(C.c_int32)]),
     "ffp_det_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, _p(C.c_double), _p(C.c_float), _p(C.c_int32)]),
+    "ffp_det_profile_detail": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, _p(C.c_double), _p(C.c_float)]),
+    "ffp_sr_profile_detail": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, _p(C.c_double), _p(C.c_float)]),
     "ffp_sr_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_void_p)]),
     "ffp_sr_destroy": (None, [C.c_void_p]),
     "ffp_sr_enhance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -243,10 +245,24 @@ class Detector:
     def profile(self) -> List[dict]:
         return _profile(self._h, lib().ffp_det_profile_count, lib().ffp_det_profile_get)
 
+    def profile_detail(self) -> List[dict]:
+        return _profile_detail(self._h, lib().ffp_det_profile_detail)
+
     def conv_stats(self) -> dict:
         fl, ms, n = C.c_double(0), C.c_float(0), C.c_int32(0)
         _check(lib().ffp_det_last_conv_stats(self._h, C.byref(fl), C.byref(ms), C.byref(n)))
         return {"flops": fl.value, "ms": ms.value, "launches": n.value}
+
+
+def _profile_detail(h, fn) -> List[dict]:
+    out, i = [], 0
+    while True:
+        name = C.create_string_buffer(128)
+        fl, ms = C.c_double(0), C.c_float(0)
+        if fn(h, i, name, 128, C.byref(fl), C.byref(ms)) != 0:
+            return out
+        out.append({"name": name.value.decode(), "flops": fl.value, "ms": ms.value})
+        i += 1
 
 
 def _profile(h, count_fn, get_fn) -> List[dict]:
@@ -325,6 +341,9 @@ class Enhancer:
 
     def profile(self) -> List[dict]:
         return _profile(self._h, lib().ffp_sr_profile_count, lib().ffp_sr_profile_get)
+
+    def profile_detail(self) -> List[dict]:
+        return _profile_detail(self._h, lib().ffp_sr_profile_detail)
 
     def conv_stats(self) -> dict:
         fl, ms, n = C.c_double(0), C.c_float(0), C.c_int32(0)

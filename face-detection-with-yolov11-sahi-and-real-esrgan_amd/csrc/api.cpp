@@ -271,6 +271,16 @@ static int profile_get(ConvProfile& p, int i, char* name, int cap, double* flops
   return FFP_OK;
 }
 
+static int detail_get(ConvProfile& p, int i, char* name, int cap, double* flops, float* ms) {
+  if (i < 0 || i >= (int)p.detail.size()) return FFP_ERR_ARG;
+  if (name && cap > 0) std::snprintf(name, cap, "%s", p.detail[i].variant.c_str());
+  if (flops) *flops = p.detail[i].flops;
+  if (ms) *ms = (float)p.detail[i].ms;
+  return FFP_OK;
+}
+int ffp_det_profile_detail(ffp_det* d, int i, char* name, int cap, double* flops, float* ms) { return d ? detail_get(d->eng.prof, i, name, cap, flops, ms) : FFP_ERR_ARG; }
+int ffp_sr_profile_detail(ffp_sr* s, int i, char* name, int cap, double* flops, float* ms) { return s ? detail_get(s->eng.prof, i, name, cap, flops, ms) : FFP_ERR_ARG; }
+
 int ffp_det_set_profile(ffp_det* d, int enable) { if (!d) return FFP_ERR_ARG; d->eng.prof.enabled = enable != 0; return FFP_OK; }
 int ffp_det_profile_count(ffp_det* d, int32_t* n) { if (!d || !n) return FFP_ERR_ARG; *n = (int)d->eng.prof.table.size(); return FFP_OK; }
 int ffp_det_profile_get(ffp_det* d, int i, char* name, int cap, double* flops, float* ms, int32_t* launches) {

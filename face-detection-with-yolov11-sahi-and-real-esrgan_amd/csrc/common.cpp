@@ -37,6 +37,12 @@ void Level::build(const std::vector<int>& hs, const std::vector<int>& ws, hipStr
   tiles.clear();
 }
 
+long long Level::count_tiles(int th) const {
+  long long t = 0;
+  for (int i = 0; i < n; ++i) t += (long long)((h[i] + th - 1) / th) * ((w[i] + 15) / 16);
+  return t;
+}
+
 const int4* Level::tile_table(int th, int* n_tiles, hipStream_t st) {
   auto it = tiles.find(th);
   if (it == tiles.end()) {

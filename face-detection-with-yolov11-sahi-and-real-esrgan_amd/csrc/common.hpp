@@ -79,6 +79,7 @@ struct Level {
 
   void build(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st);
   const int4* tile_table(int th, int* n_tiles, hipStream_t st);
+  long long count_tiles(int th) const;
 };
 
 // A view of `C` channels starting at `coff` inside pixel records of `cs` elements.

@@ -87,20 +87,38 @@ template <> __device__ __forceinline__ void store4<_Float16>(_Float16* p, const 
   *reinterpret_cast<uint2*>(p) = v.u;
 }
 
+// compile-time geometry shared by the kernel and its launcher
+template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int KC> struct Geo {
+  static constexpr int ES = sizeof(T);
+  static constexpr int KG = MM<T>::KG;
+  static constexpr int KCG = KC / KG;                       // k-groups per chunk
+  static constexpr int FR = WM * MI;                        // pixel fragments per workgroup (32 px each)
+  static constexpr int TH = FR * 2;                         // output tile rows (16 columns)
+  static constexpr int HH = KS == 1 ? 1 : (TH - 1) * STRIDE + KS;
+  static constexpr int HW = KS == 1 ? FR * 32 : 15 * STRIDE + KS;
+  static constexpr int NPIX = HH * HW;                      // staged input pixels
+  static constexpr int PS = KC * ES + 16;                   // LDS bytes per pixel record (+1 b128 pad against bank conflicts)
+  static constexpr int VPP = KC * ES / 16;                  // 16-byte vectors per pixel per chunk
+  static constexpr int EPV = 16 / ES;                       // elements per vector
+  static constexpr int TAPS = KS * KS;
+  static constexpr int NTB = WN * NIW;                      // 32-channel tiles per workgroup
+  static constexpr int IN_BYTES = (NPIX * PS + 15) / 16 * 16;
+  static constexpr int W_FRAGS = NTB * TAPS * KCG;          // 1 KiB weight fragments per chunk
+  static constexpr int BUF = IN_BYTES + W_FRAGS * 1024;     // one LDS stage: input tile chunk + its weights
+  static constexpr int LDS = 2 * BUF;                       // double buffered
+  static constexpr int NVI = NPIX * VPP, NVW = W_FRAGS * 64;
+  static constexpr int RI = (NVI + 255) / 256, RW = (NVW + 255) / 256;   // prefetch registers (16 B each) per thread
+  static_assert(KC % KG == 0 && WM * WN == 4, "geometry");
+};
+
+// Main loop: per chunk of KC input channels the input halo tile AND the chunk's weight fragments live in one LDS stage;
+// chunk c+1 is fetched global->registers while chunk c is multiplied out of LDS (no global access inside the MFMA
+// loop), then written to the other stage: one barrier per chunk.
 template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int KC>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a) {
-  static_assert(WM * WN == 4, "4 waves");
-  constexpr int ES = sizeof(T);
-  constexpr int KG = MM<T>::KG;
-  constexpr int FR = WM * MI;                       // pixel fragments per workgroup (32 px each)
-  constexpr int TH = FR * 2;                        // output tile rows (16 columns)
-  constexpr int HH = KS == 1 ? 1 : (TH - 1) * STRIDE + KS;
-  constexpr int HW = KS == 1 ? FR * 32 : 15 * STRIDE + KS;
-  constexpr int NPIX = HH * HW;                     // staged input pixels
-  constexpr int PS = KC * ES + 16;                  // LDS bytes per pixel record (+1 b128 pad against bank conflicts)
-  constexpr int VPP = KC * ES / 16;                 // 16-byte vectors per pixel per chunk
-  constexpr int EPV = 16 / ES;                      // elements per vector
-  constexpr int TAPS = KS * KS;
+  using G = Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>;
+  constexpr int ES = G::ES, KG = G::KG, KCG = G::KCG, HW = G::HW, NPIX = G::NPIX, PS = G::PS, VPP = G::VPP, EPV = G::EPV;
+  constexpr int TAPS = G::TAPS, NTB = G::NTB, RI = G::RI, RW = G::RW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -131,14 +149,78 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a) {
     const int pix = KS == 1 ? f * 32 + p : ((2 * f + (p >> 4)) * STRIDE) * HW + (p & 15) * STRIDE;
     boff[mi] = pix * PS + hh * 16;
   }
-  const unsigned char* wlane = reinterpret_cast<const unsigned char*>(a.wpk) + lane * 16;
   const int ntile0 = (nblk * WN + wn) * NIW;
-  size_t wrow[NIW];
+  const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in);
+  const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.wpk);
+
+  // per-thread staging slots: which global vector each of this thread's RI + RW registers carries (chunk independent part)
+  long long isrc[RI];          // byte offset of the pixel record (-1: outside the image -> zeros)
+  int ivec[RI];                // vector index inside the chunk
 #pragma unroll
-  for (int ni = 0; ni < NIW; ++ni) {
-    const int nt = min(ntile0 + ni, a.ntiles32 - 1);
-    wrow[ni] = (size_t)nt * TAPS * a.ncg * 1024;
+  for (int i = 0; i < RI; ++i) {
+    const int idx = tid + i * 256;
+    isrc[i] = -1; ivec[i] = 0;
+    if (idx < G::NVI) {
+      const int hp = idx / VPP;
+      ivec[i] = idx % VPP;
+      long long gp;
+      bool ok;
+      if (KS == 1) {
+        gp = in_base + hp;
+        ok = gp < a.total_px;
+      } else {
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+        gp = in_base + (long long)(iy >> a.up) * Wi + (ix >> a.up);
+      }
+      if (ok) isrc[i] = ((long long)gp * a.in_cs + a.in_coff) * ES;
+    }
   }
+  long long wsrc[RW];          // byte offset of the fragment row start for k-group 0 (-1: no such slot)
+  int wkg[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    const int idx = tid + i * 256;
+    wsrc[i] = -1; wkg[i] = 0;
+    if (idx < G::NVW) {
+      const int fl = idx >> 6, l = idx & 63;
+      const int kg = fl % KCG, tap = (fl / KCG) % TAPS, ntl = fl / (KCG * TAPS);
+      const int nt = min(nblk * NTB + ntl, a.ntiles32 - 1);
+      wkg[i] = kg;
+      wsrc[i] = ((long long)(nt * TAPS + tap) * a.ncg) * 1024 + l * 16;
+    }
+  }
+
+  uint4 ri[RI], rw[RW];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      const int c = c0 + ivec[i] * EPV;
+      if (isrc[i] >= 0 && c < a.cin) v = *reinterpret_cast<const uint4*>(inb + isrc[i] + (long long)c * ES);
+      ri[i] = v;
+    }
+    const int cg0 = c0 / KG;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (wsrc[i] >= 0 && cg0 + wkg[i] < a.ncg) v = *reinterpret_cast<const uint4*>(wb + wsrc[i] + (long long)(cg0 + wkg[i]) * 1024);
+      rw[i] = v;
+    }
+  };
+  auto stash = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < G::NVI) *reinterpret_cast<uint4*>(buf + (idx / VPP) * PS + (idx % VPP) * 16) = ri[i];
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < G::NVW) *reinterpret_cast<uint4*>(buf + G::IN_BYTES + idx * 16) = rw[i];
+    }
+  };
 
   f32x16 acc[NIW][MI];
 #pragma unroll
@@ -148,54 +230,38 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
-  const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in);
-
+  fetch(0);
+  stash(smem);
+  __syncthreads();
+  int cur = 0;
   for (int c0 = 0; c0 < a.cin; c0 += KC) {
-    if (c0) __syncthreads();
-    // ---- stage the input (halo) tile chunk: global -> registers -> LDS, zero fill outside the image / past Cin
-#pragma unroll 4
-    for (int i = tid; i < NPIX * VPP; i += 256) {
-      const int hp = i / VPP, v = i % VPP;
-      const int c = c0 + v * EPV;
-      uint4 val = make_uint4(0u, 0u, 0u, 0u);
-      if (c < a.cin) {
-        long long gp;
-        bool ok;
-        if (KS == 1) {
-          gp = in_base + hp;
-          ok = gp < a.total_px;
-        } else {
-          const int hy = hp / HW, hx = hp - hy * HW;
-          const int iy = iy0 + hy, ix = ix0 + hx;
-          ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-          gp = in_base + (long long)(iy >> a.up) * Wi + (ix >> a.up);
-        }
-        if (ok) val = *reinterpret_cast<const uint4*>(inb + ((size_t)gp * a.in_cs + a.in_coff + c) * ES);
-      }
-      *reinterpret_cast<uint4*>(smem + hp * PS + v * 16) = val;
-    }
-    __syncthreads();
-
+    const bool more = c0 + KC < a.cin;
+    if (more) fetch(c0 + KC);                              // in flight while this chunk is multiplied
+    const unsigned char* sb = smem + cur * G::BUF;
+    const unsigned char* sw = sb + G::IN_BYTES + ((wn * NIW) * TAPS * KCG) * 1024 + lane * 16;
     const int kmax = min(KC, a.cin_pad - c0) / KG;
-    const int cg0 = c0 / KG;
-    for (int ks = 0; ks < kmax; ++ks) {
-      const unsigned char* wk = wlane + (size_t)(cg0 + ks) * 1024;
-      const unsigned char* sk = smem + ks * (KG * ES);
 #pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
-        const int ky = tap / KS, kx = tap % KS;
-        uint4 bf[MI];
+    for (int ks = 0; ks < KCG; ++ks) {
+      if (ks < kmax) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          bf[mi] = *reinterpret_cast<const uint4*>(sk + boff[mi] + (ky * HW + kx) * PS);
+        for (int tap = 0; tap < TAPS; ++tap) {
+          const int ky = tap / KS, kx = tap % KS;
+          uint4 bf[MI];
 #pragma unroll
-        for (int ni = 0; ni < NIW; ++ni) {
-          const uint4 af = *reinterpret_cast<const uint4*>(wk + wrow[ni] + (size_t)tap * a.ncg * 1024);
+          for (int mi = 0; mi < MI; ++mi)
+            bf[mi] = *reinterpret_cast<const uint4*>(sb + boff[mi] + (ky * HW + kx) * PS + ks * (KG * ES));
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) MM<T>::mma(acc[ni][mi], af, bf[mi]);
+          for (int ni = 0; ni < NIW; ++ni) {
+            const uint4 af = *reinterpret_cast<const uint4*>(sw + ((ni * TAPS + tap) * KCG + ks) * 1024);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) MM<T>::mma(acc[ni][mi], af, bf[mi]);
+          }
         }
       }
     }
+    if (more) stash(smem + (cur ^ 1) * G::BUF);            // the other stage was last read one barrier ago
+    __syncthreads();
+    cur ^= 1;
   }
 
   // ---- epilogue: bias, activation, residual(s), store. Lane = one pixel; regs 4g..4g+3 = channels 8g+4hh..+3.
@@ -265,14 +331,11 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a) {
 namespace {
 
 template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int KC> struct Cfg {
-  static constexpr int ES = sizeof(T);
-  static constexpr int FR = WM * MI;
-  static constexpr int TH = FR * 2;
-  static constexpr int HH = KS == 1 ? 1 : (TH - 1) * STRIDE + KS;
-  static constexpr int HW = KS == 1 ? FR * 32 : 15 * STRIDE + KS;
-  static constexpr int LDS = HH * HW * (KC * ES + 16);
-  static constexpr int BLOCK_PX = FR * 32;
-  static constexpr int BLOCK_N = WN * NIW * 32;
+  using G = Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>;
+  static constexpr int LDS = G::LDS;
+  static constexpr int BLOCK_PX = G::FR * 32;
+  static constexpr int BLOCK_N = G::NTB * 32;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
   static auto kernel() { return &conv_mfma_kernel<T, KS, STRIDE, WM, WN, MI, NIW, KC>; }
   static void init() {
     FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel()), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -282,7 +345,7 @@ template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int K
     if (KS == 1) {
       n_tiles = (int)((a.total_px + BLOCK_PX - 1) / BLOCK_PX);
     } else {
-      a.tiles = out_lvl->tile_table(TH, &n_tiles, st);
+      a.tiles = out_lvl->tile_table(G::TH, &n_tiles, st);
     }
     a.n_nblk = (a.ntiles32 * 32 + BLOCK_N - 1) / BLOCK_N;
     const int grid = n_tiles * a.n_nblk;
@@ -291,29 +354,87 @@ template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int K
   }
 };
 
-// chunk sizes (input channels staged per barrier pair)
-template <typename T, int KS, int STRIDE> struct KCof;
-template <> struct KCof<float, 1, 1> { static constexpr int v = 64; };
-template <> struct KCof<float, 3, 1> { static constexpr int v = 32; };
-template <> struct KCof<float, 3, 2> { static constexpr int v = 16; };
-template <> struct KCof<_Float16, 1, 1> { static constexpr int v = 128; };
-template <> struct KCof<_Float16, 3, 1> { static constexpr int v = 64; };
-template <> struct KCof<_Float16, 3, 2> { static constexpr int v = 32; };
+// chunk sizes (input channels per LDS stage), chosen so that 2 x (input tile + weight fragments) fits the 160 KiB LDS
+//                                   shape: 0 wide, 1 narrow2, 2 narrow1
+template <typename T, int KS, int STRIDE, int SHAPE> struct KCof;
+template <> struct KCof<float, 1, 1, 0> { static constexpr int v = 32; };
+template <> struct KCof<float, 1, 1, 1> { static constexpr int v = 32; };
+template <> struct KCof<float, 1, 1, 2> { static constexpr int v = 64; };
+template <> struct KCof<float, 3, 1, 0> { static constexpr int v = 8; };
+template <> struct KCof<float, 3, 1, 1> { static constexpr int v = 16; };
+template <> struct KCof<float, 3, 1, 2> { static constexpr int v = 16; };
+template <> struct KCof<float, 3, 2, 0> { static constexpr int v = 8; };
+template <> struct KCof<float, 3, 2, 1> { static constexpr int v = 16; };
+template <> struct KCof<float, 3, 2, 2> { static constexpr int v = 16; };
+template <> struct KCof<_Float16, 1, 1, 0> { static constexpr int v = 64; };
+template <> struct KCof<_Float16, 1, 1, 1> { static constexpr int v = 64; };
+template <> struct KCof<_Float16, 1, 1, 2> { static constexpr int v = 128; };
+template <> struct KCof<_Float16, 3, 1, 0> { static constexpr int v = 16; };
+template <> struct KCof<_Float16, 3, 1, 1> { static constexpr int v = 32; };
+template <> struct KCof<_Float16, 3, 1, 2> { static constexpr int v = 32; };
+template <> struct KCof<_Float16, 3, 2, 0> { static constexpr int v = 16; };
+template <> struct KCof<_Float16, 3, 2, 1> { static constexpr int v = 32; };
+template <> struct KCof<_Float16, 3, 2, 2> { static constexpr int v = 32; };
 
+// Shape selection: six workgroup shapes per (dtype, k, stride) — {wide 128ch, narrow2 64ch, narrow1 32ch} x {full, half
+// pixel tile}. The largest block (most operand reuse) that still yields >= 2 workgroups per CU wins; layers with few
+// pixels (stride-32 maps, face crops) fall through to smaller blocks so that the whole chip is busy.
 template <typename T, int KS, int STRIDE> struct Family {
-  static constexpr int KC = KCof<T, KS, STRIDE>::v;
   static constexpr int MIW = STRIDE == 2 ? 2 : 4;   // wide: 2x2 waves
   static constexpr int MIN = STRIDE == 2 ? 1 : 2;   // narrow: 4x1 waves
-  using Wide = Cfg<T, KS, STRIDE, 2, 2, MIW, 2, KC>;
-  using Narrow2 = Cfg<T, KS, STRIDE, 4, 1, MIN, 2, KC>;
-  using Narrow1 = Cfg<T, KS, STRIDE, 4, 1, MIN, 1, KC>;
-  static void init() { Wide::init(); Narrow2::init(); Narrow1::init(); }
+  static constexpr int MIWH = MIW / 2;
+  static constexpr int MINH = MIN > 1 ? MIN / 2 : 1;
+  using Wide = Cfg<T, KS, STRIDE, 2, 2, MIW, 2, KCof<T, KS, STRIDE, 0>::v>;
+  using Narrow2 = Cfg<T, KS, STRIDE, 4, 1, MIN, 2, KCof<T, KS, STRIDE, 1>::v>;
+  using Narrow1 = Cfg<T, KS, STRIDE, 4, 1, MIN, 1, KCof<T, KS, STRIDE, 2>::v>;
+  using WideH = Cfg<T, KS, STRIDE, 2, 2, MIWH, 2, KCof<T, KS, STRIDE, 0>::v>;
+  using Narrow2H = Cfg<T, KS, STRIDE, 4, 1, MINH, 2, KCof<T, KS, STRIDE, 1>::v>;
+  using Narrow1H = Cfg<T, KS, STRIDE, 4, 1, MINH, 1, KCof<T, KS, STRIDE, 2>::v>;
+  static constexpr bool HAS_NH = MIN > 1;
+  static void init() {
+    Wide::init(); Narrow2::init(); Narrow1::init(); WideH::init();
+    if (HAS_NH) { Narrow2H::init(); Narrow1H::init(); }
+  }
+  template <class C> static long long wgs(const ConvArgs& a, Level* out_lvl) {
+    const long long tiles = KS == 1 ? (a.total_px + C::BLOCK_PX - 1) / C::BLOCK_PX : out_lvl->count_tiles(C::G::TH);
+    return tiles * ((a.ntiles32 * 32 + C::BLOCK_N - 1) / C::BLOCK_N);
+  }
+  static int choose(const ConvArgs& a, Level* out_lvl) {
+    constexpr long long ENOUGH = 2 * 256;
+    int best = -1;
+    long long best_n = -1;
+    auto consider = [&](int id, long long n, bool valid) {
+      if (!valid || best_n >= ENOUGH) return;
+      if (n >= ENOUGH || n > best_n) { best = id; best_n = n; }
+    };
+    consider(0, wgs<Wide>(a, out_lvl), a.ntiles32 >= 3);
+    consider(1, wgs<WideH>(a, out_lvl), a.ntiles32 >= 3);
+    consider(2, wgs<Narrow2>(a, out_lvl), a.ntiles32 >= 2);
+    if (HAS_NH) consider(3, wgs<Narrow2H>(a, out_lvl), a.ntiles32 >= 2);
+    consider(4, wgs<Narrow1>(a, out_lvl), true);
+    if (HAS_NH) consider(5, wgs<Narrow1H>(a, out_lvl), true);
+    return best;
+  }
   static void launch(ConvArgs& a, Level* out_lvl, hipStream_t st) {
-    if (a.ntiles32 >= 3) Wide::launch(a, out_lvl, st);
-    else if (a.ntiles32 == 2) Narrow2::launch(a, out_lvl, st);
-    else Narrow1::launch(a, out_lvl, st);
+    switch (choose(a, out_lvl)) {
+      case 0: Wide::launch(a, out_lvl, st); break;
+      case 1: WideH::launch(a, out_lvl, st); break;
+      case 2: Narrow2::launch(a, out_lvl, st); break;
+      case 3: Narrow2H::launch(a, out_lvl, st); break;
+      case 4: Narrow1::launch(a, out_lvl, st); break;
+      default: Narrow1H::launch(a, out_lvl, st); break;
+    }
   }
 };
+
+static const char* kShapeNames[6] = {"wide", "wideH", "narrow2", "narrow2H", "narrow1", "narrow1H"};
+
+template <typename T> int choose_t(const ConvArgs& a, int k, int stride, Level* out_lvl) {
+  if (k == 1 && stride == 1) return Family<T, 1, 1>::choose(a, out_lvl);
+  if (k == 3 && stride == 1) return Family<T, 3, 1>::choose(a, out_lvl);
+  if (k == 3 && stride == 2) return Family<T, 3, 2>::choose(a, out_lvl);
+  return 4;
+}
 
 template <typename T> void launch_t(ConvArgs& a, int k, int stride, Level* out_lvl, hipStream_t st) {
   if (k == 1 && stride == 1) Family<T, 1, 1>::launch(a, out_lvl, st);
@@ -332,7 +453,7 @@ void conv_kernels_init() {
   done = true;
 }
 
-void launch_conv(const ConvOp& op, hipStream_t st) {
+static ConvArgs make_args(const ConvOp& op) {
   const PackedConv& pc = *op.pc;
   FFP_CHECK(!pc.depthwise(), FFP_ERR_ARG, "conv %s: depthwise goes through launch_dwconv", pc.name.c_str());
   FFP_CHECK(op.in.dt == pc.dt, FFP_ERR_ARG, "conv %s: input dtype differs from packed weights", pc.name.c_str());
@@ -367,9 +488,26 @@ void launch_conv(const ConvOp& op, hipStream_t st) {
   }
   a.vec_ok = vec ? 1 : 0;
   if (pc.k == 1) FFP_CHECK(op.in.lvl->total_px == op.out.lvl->total_px, FFP_ERR_ARG, "conv %s: 1x1 levels differ", pc.name.c_str());
+  return a;
+}
+
+void launch_conv(const ConvOp& op, hipStream_t st) {
+  const PackedConv& pc = *op.pc;
+  if (conv_direct_eligible(op)) { launch_conv_direct(op, st); return; }
+  ConvArgs a = make_args(op);
   if (pc.dt == F32) launch_t<float>(a, pc.k, op.stride, op.out.lvl, st);
   else launch_t<_Float16>(a, pc.k, op.stride, op.out.lvl, st);
   FFP_HIP(hipGetLastError());
+}
+
+std::string conv_variant(const ConvOp& op) {
+  const PackedConv& pc = *op.pc;
+  if (conv_direct_eligible(op)) return std::string(pc.dt == F32 ? "f32" : "f16") + "_k3_direct";
+  const ConvArgs a = make_args(op);
+  const int shape = pc.dt == F32 ? choose_t<float>(a, pc.k, op.stride, op.out.lvl) : choose_t<_Float16>(a, pc.k, op.stride, op.out.lvl);
+  char buf[64];
+  snprintf(buf, sizeof(buf), "%s_k%ds%d_%s", pc.dt == F32 ? "f32" : "f16", pc.k, op.stride, kShapeNames[shape < 0 ? 4 : shape]);
+  return buf;
 }
 
 }  // namespace ffp

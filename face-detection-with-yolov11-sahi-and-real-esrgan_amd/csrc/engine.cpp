@@ -1,6 +1,8 @@
 // engine.cpp — plan bookkeeping and conv-kernel profiling.
 #include "engine.hpp"
 
+#include <cstdlib>
+
 namespace ffp {
 
 ConvProfile::~ConvProfile() {
@@ -10,6 +12,7 @@ ConvProfile::~ConvProfile() {
 void ConvProfile::begin() {
   table.clear();
   pending.clear();
+  detail.clear();
 }
 
 int ConvProfile::open(hipStream_t st) {
@@ -24,9 +27,9 @@ int ConvProfile::open(hipStream_t st) {
   return slot;
 }
 
-void ConvProfile::close(int slot, hipStream_t st, const std::string& variant, double flops) {
+void ConvProfile::close(int slot, hipStream_t st, const std::string& variant, double flops, const std::string& name) {
   FFP_HIP(hipEventRecord(ev[slot].second, st));
-  pending.push_back({slot, variant, flops});
+  pending.push_back({slot, variant, flops, name});
 }
 
 void ConvProfile::collect() {
@@ -38,17 +41,11 @@ void ConvProfile::collect() {
     e.flops += p.flops;
     e.ms += ms;
     e.launches += 1;
+    Entry d;
+    d.variant = p.variant + " " + p.name; d.flops = p.flops; d.ms = ms; d.launches = 1;
+    detail.push_back(d);
   }
   pending.clear();
-}
-
-std::string conv_variant(const ConvOp& op) {
-  const PackedConv& pc = *op.pc;
-  const int nt = pc.cout_pad / 32;
-  char buf[64];
-  snprintf(buf, sizeof(buf), "%s_k%ds%d_%s", pc.dt == F32 ? "f32" : "f16", pc.k, op.stride,
-           nt >= 3 ? "wide" : nt == 2 ? "narrow2" : "narrow1");
-  return buf;
 }
 
 Level* Plan::add_level(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st) {
@@ -72,6 +69,7 @@ void Plan::add_conv(const ConvOp& op) {
   o.flops = conv_flops_of(*op.pc, op.out.lvl->total_px);
   s.is_conv = true;
   s.variant = conv_variant(o);
+  s.name = op.pc->name;
   s.flops = o.flops;
   s.run = [o](hipStream_t st) { launch_conv(o, st); };
   conv_flops += o.flops;
@@ -79,17 +77,66 @@ void Plan::add_conv(const ConvOp& op) {
   steps.push_back(std::move(s));
 }
 
+Plan::~Plan() {
+  if (gexec) (void)hipGraphExecDestroy(gexec);
+  if (graph) (void)hipGraphDestroy(graph);
+}
+
+static bool graphs_enabled() {
+  static const bool on = [] { const char* e = getenv("FFP_NO_GRAPH"); return !(e && e[0] == '1'); }();
+  return on;
+}
+
 void Plan::execute(hipStream_t st, ConvProfile* prof) {
   const bool p = prof && prof->enabled;
-  for (Step& s : steps) {
-    if (p && s.is_conv) {
-      const int slot = prof->open(st);
-      s.run(st);
-      prof->close(slot, st, s.variant, s.flops);
-    } else {
-      s.run(st);
+  if (p) {                                   // per-launch events: always eager
+    for (Step& s : steps) {
+      if (s.is_conv) {
+        const int slot = prof->open(st);
+        s.run(st);
+        prof->close(slot, st, s.variant, s.flops, s.name);
+      } else {
+        s.run(st);
+      }
+    }
+    return;
+  }
+  if (runs > 0 && graph_ok && graphs_enabled()) {
+    if (!gexec) {
+      // first eager run has built every lazily created table; capture the identical sequence now
+      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        bool ok = true;
+        try {
+          for (Step& s : steps) s.run(st);
+        } catch (...) {
+          ok = false;
+        }
+        hipGraph_t g = nullptr;
+        if (hipStreamEndCapture(st, &g) != hipSuccess || !ok || !g) {
+          graph_ok = false;
+          if (g) (void)hipGraphDestroy(g);
+          (void)hipGetLastError();
+        } else if (hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0) != hipSuccess) {
+          graph_ok = false;
+          gexec = nullptr;
+          (void)hipGraphDestroy(g);
+          (void)hipGetLastError();
+        } else {
+          graph = g;
+        }
+      } else {
+        graph_ok = false;
+        (void)hipGetLastError();
+      }
+    }
+    if (gexec) {
+      FFP_HIP(hipGraphLaunch(gexec, st));
+      ++runs;
+      return;
     }
   }
+  for (Step& s : steps) s.run(st);
+  ++runs;
 }
 
 }  // namespace ffp

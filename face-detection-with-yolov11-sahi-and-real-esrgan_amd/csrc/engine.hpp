@@ -14,13 +14,14 @@ struct ConvProfile {
   struct Entry { std::string variant; double flops = 0; double ms = 0; int launches = 0; };
   bool enabled = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // recycled pool
-  struct Pending { int ev; std::string variant; double flops; };
+  struct Pending { int ev; std::string variant; double flops; std::string name; };
+  std::vector<Entry> detail;                      // one entry per launch of the last call (variant = "<variant> <layer name>")
   std::vector<Pending> pending;
   std::map<std::string, Entry> table;
   ~ConvProfile();
   void begin();                                  // clear the table, start collecting
   int open(hipStream_t st);                      // record a start event, returns slot
-  void close(int slot, hipStream_t st, const std::string& variant, double flops);
+  void close(int slot, hipStream_t st, const std::string& variant, double flops, const std::string& name);
   void collect();                                // after the stream has drained
 };
 
@@ -30,7 +31,7 @@ std::string conv_variant(const ConvOp& op);
 struct Step {
   std::function<void(hipStream_t)> run;
   bool is_conv = false;
-  std::string variant;
+  std::string variant, name;
   double flops = 0;
 };
 
@@ -41,6 +42,13 @@ struct Plan {
   double conv_flops = 0;
   int conv_launches = 0;
   size_t bytes = 0;
+  // The launch sequence of a plan is fixed (every pointer is plan-owned), so after one eager run it is captured into a
+  // hipGraph and replayed: ~110 (detector) / ~355 (SR) launches per frame become one graph launch.
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  int runs = 0;
+  bool graph_ok = true;
+  ~Plan();
 
   Level* add_level(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st);
   TView alloc(Level* l, int C, DType dt);

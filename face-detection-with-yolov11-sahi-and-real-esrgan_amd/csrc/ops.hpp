@@ -20,6 +20,9 @@ struct ConvOp {
   double flops = 0;   // 2*MAC, algorithmic (unpadded)
 };
 void launch_conv(const ConvOp& op, hipStream_t st);
+// image-input 3x3 convs (3 real channels: YOLO stem, ESRGAN conv_first) as a direct VALU kernel (ops_misc.hip)
+bool conv_direct_eligible(const ConvOp& op);
+void launch_conv_direct(const ConvOp& op, hipStream_t st);
 void conv_kernels_init();   // raise dynamic-LDS limits once per process
 
 // Depthwise 3x3, stride 1 (YOLO11 cls-tower DWConv and the PSA positional conv), fp32 math.

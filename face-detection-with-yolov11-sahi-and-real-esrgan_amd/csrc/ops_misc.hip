@@ -25,22 +25,38 @@ __device__ __forceinline__ int find_img(const int4* tab, int n, long long gp) {
   return lo;
 }
 
-// ---- depthwise 3x3 s1 p1 --------------------------------------------------------------------------------------
+// 4 consecutive channels as floats (16-byte fp32 / 8-byte fp16 accesses)
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<_Float16>(const _Float16* p) {
+  union { uint2 u; _Float16 h[4]; } v;
+  v.u = *reinterpret_cast<const uint2*>(p);
+  return make_float4((float)v.h[0], (float)v.h[1], (float)v.h[2], (float)v.h[3]);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<_Float16>(_Float16* p, float4 v) {
+  union { uint2 u; _Float16 h[4]; } o;
+  o.h[0] = (_Float16)v.x; o.h[1] = (_Float16)v.y; o.h[2] = (_Float16)v.z; o.h[3] = (_Float16)v.w;
+  *reinterpret_cast<uint2*>(p) = o.u;
+}
+
+// ---- depthwise 3x3 s1 p1: one thread = one pixel x 4 channels ------------------------------------------------------
 template <typename T>
 __global__ void dwconv3x3_kernel(const T* __restrict__ in, int in_cs, int in_coff, int grp, int grp_stride, int grp_off,
                                  T* __restrict__ out, int out_cs, int out_coff, const float* __restrict__ w /*[9][C]*/,
                                  const float* __restrict__ bias, const T* __restrict__ res, int r_cs, int r_coff, int C,
                                  int act, const int4* __restrict__ tab, int n_img, long long total_px) {
+  const int C4 = C >> 2;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = total_px * C;
-  if (idx >= total) return;
-  const int c = (int)(idx % C);
-  const long long gp = idx / C;
+  if (idx >= total_px * C4) return;
+  const int c = (int)(idx % C4) * 4;
+  const long long gp = idx / C4;
   const int im = find_img(tab, n_img, gp);
   const int4 t = tab[im];
   const int lp = (int)(gp - t.x), y = lp / t.z, x = lp - y * t.z;
   const int cin = in_coff + (c / grp) * grp_stride + grp_off + (c % grp);
-  float acc = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int yy = y + ky - 1;
@@ -49,58 +65,111 @@ __global__ void dwconv3x3_kernel(const T* __restrict__ in, int in_cs, int in_cof
     for (int kx = 0; kx < 3; ++kx) {
       const int xx = x + kx - 1;
       if ((unsigned)xx >= (unsigned)t.z) continue;
-      acc = fmaf(ldf(in + ((size_t)t.x + (size_t)yy * t.z + xx) * in_cs + cin), w[(ky * 3 + kx) * C + c], acc);
+      const float4 v = ld4<T>(in + ((size_t)t.x + (size_t)yy * t.z + xx) * in_cs + cin);
+      const float4 k = *reinterpret_cast<const float4*>(w + (ky * 3 + kx) * C + c);
+      acc.x = fmaf(v.x, k.x, acc.x); acc.y = fmaf(v.y, k.y, acc.y); acc.z = fmaf(v.z, k.z, acc.z); acc.w = fmaf(v.w, k.w, acc.w);
     }
   }
-  float v = act_fn(acc + bias[c], act);
-  if (res) v += ldf(res + (size_t)gp * r_cs + r_coff + c);
-  stf(out + (size_t)gp * out_cs + out_coff + c, v);
+  const float4 b = *reinterpret_cast<const float4*>(bias + c);
+  float4 v = make_float4(act_fn(acc.x + b.x, act), act_fn(acc.y + b.y, act), act_fn(acc.z + b.z, act), act_fn(acc.w + b.w, act));
+  if (res) {
+    const float4 r = ld4<T>(res + (size_t)gp * r_cs + r_coff + c);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  st4<T>(out + (size_t)gp * out_cs + out_coff + c, v);
 }
 
-// ---- SPPF pooling: 5x5, 9x9, 13x13 windows (== 3 chained 5x5 pools with -inf padding) ----------------------------
+// ---- SPPF pooling: 5x5, 9x9, 13x13 windows (== 3 chained 5x5 pools with -inf padding), pixel x 4 channels per thread
 template <typename T>
 __global__ void sppf_pool_kernel(const T* __restrict__ in, int in_cs, int in_coff, T* __restrict__ y1, T* __restrict__ y2,
                                  T* __restrict__ y3, int o_cs, int o1, int o2, int o3, int C, const int4* __restrict__ tab,
                                  int n_img, long long total_px) {
+  const int C4 = C >> 2;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total_px * C) return;
-  const int c = (int)(idx % C);
-  const long long gp = idx / C;
+  if (idx >= total_px * C4) return;
+  const int c = (int)(idx % C4) * 4;
+  const long long gp = idx / C4;
   const int im = find_img(tab, n_img, gp);
   const int4 t = tab[im];
   const int lp = (int)(gp - t.x), y = lp / t.z, x = lp - y * t.z;
-  float m5 = -INFINITY, m9 = -INFINITY, m13 = -INFINITY;
+  const float ninf = -INFINITY;
+  float4 m5 = make_float4(ninf, ninf, ninf, ninf), m9 = m5, m13 = m5;
   for (int dy = -6; dy <= 6; ++dy) {
     const int yy = y + dy;
     if ((unsigned)yy >= (unsigned)t.y) continue;
     for (int dx = -6; dx <= 6; ++dx) {
       const int xx = x + dx;
       if ((unsigned)xx >= (unsigned)t.z) continue;
-      const float v = ldf(in + ((size_t)t.x + (size_t)yy * t.z + xx) * in_cs + in_coff + c);
+      const float4 v = ld4<T>(in + ((size_t)t.x + (size_t)yy * t.z + xx) * in_cs + in_coff + c);
       const int r = max(abs(dy), abs(dx));
-      m13 = fmaxf(m13, v);
-      if (r <= 4) m9 = fmaxf(m9, v);
-      if (r <= 2) m5 = fmaxf(m5, v);
+      m13.x = fmaxf(m13.x, v.x); m13.y = fmaxf(m13.y, v.y); m13.z = fmaxf(m13.z, v.z); m13.w = fmaxf(m13.w, v.w);
+      if (r <= 4) { m9.x = fmaxf(m9.x, v.x); m9.y = fmaxf(m9.y, v.y); m9.z = fmaxf(m9.z, v.z); m9.w = fmaxf(m9.w, v.w); }
+      if (r <= 2) { m5.x = fmaxf(m5.x, v.x); m5.y = fmaxf(m5.y, v.y); m5.z = fmaxf(m5.z, v.z); m5.w = fmaxf(m5.w, v.w); }
     }
   }
-  stf(y1 + (size_t)gp * o_cs + o1 + c, m5);
-  stf(y2 + (size_t)gp * o_cs + o2 + c, m9);
-  stf(y3 + (size_t)gp * o_cs + o3 + c, m13);
+  st4<T>(y1 + (size_t)gp * o_cs + o1 + c, m5);
+  st4<T>(y2 + (size_t)gp * o_cs + o2 + c, m9);
+  st4<T>(y3 + (size_t)gp * o_cs + o3 + c, m13);
 }
 
-// ---- nearest x2 ---------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void upsample2x_kernel(const T* __restrict__ in, int in_cs, int in_coff, const int4* __restrict__ in_tab,
-                                  T* __restrict__ out, int out_cs, int out_coff, const int4* __restrict__ out_tab, int n_img,
-                                  int C, long long total_out_px) {
+// ---- nearest x2: one thread copies 16 bytes ---------------------------------------------------------------------------
+__global__ void upsample2x_kernel(const unsigned char* __restrict__ in, int in_cs_b, int in_coff_b, const int4* __restrict__ in_tab,
+                                  unsigned char* __restrict__ out, int out_cs_b, int out_coff_b, const int4* __restrict__ out_tab,
+                                  int n_img, int nvec, long long total_out_px) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total_out_px * C) return;
-  const int c = (int)(idx % C);
-  const long long gp = idx / C;
+  if (idx >= total_out_px * nvec) return;
+  const int v = (int)(idx % nvec);
+  const long long gp = idx / nvec;
   const int im = find_img(out_tab, n_img, gp);
   const int4 to = out_tab[im], ti = in_tab[im];
   const int lp = (int)(gp - to.x), y = lp / to.z, x = lp - y * to.z;
-  out[(size_t)gp * out_cs + out_coff + c] = in[((size_t)ti.x + (size_t)(y >> 1) * ti.z + (x >> 1)) * in_cs + in_coff + c];
+  const uint4 d = *reinterpret_cast<const uint4*>(in + ((size_t)ti.x + (size_t)(y >> 1) * ti.z + (x >> 1)) * in_cs_b + in_coff_b + v * 16);
+  *reinterpret_cast<uint4*>(out + (size_t)gp * out_cs_b + out_coff_b + v * 16) = d;
+}
+
+// ---- direct 3x3 conv for image inputs (3 real channels, NHWC4 fp32 / NHWC8 fp16): one thread = one output pixel x COUT ----
+// HBM-bound (27 inputs in, COUT out per pixel); weights [tap][3][COUT] broadcast from LDS.
+template <typename T, int COUT>
+__global__ void __launch_bounds__(256) conv3x3_c3_direct_kernel(const T* __restrict__ in, int in_cs, T* __restrict__ out, int out_cs, int out_coff,
+                                                                const float* __restrict__ w, const float* __restrict__ bias, int stride, int act,
+                                                                const int4* __restrict__ in_tab, const int4* __restrict__ out_tab, int n_img,
+                                                                long long total_out_px) {
+  __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
+  for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = w[i];
+  __syncthreads();
+  const long long gp = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gp >= total_out_px) return;
+  const int im = find_img(out_tab, n_img, gp);
+  const int4 to = out_tab[im], ti = in_tab[im];
+  const int lp = (int)(gp - to.x), oy = lp / to.z, ox = lp - oy * to.z;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {        // taps stay a loop: unrolling all 27 x COUT/4 LDS reads spills
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+    float px[3] = {0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)ti.y && (unsigned)ix < (unsigned)ti.z) {
+      const float4 v = ld4<T>(in + ((size_t)ti.x + (size_t)iy * ti.z + ix) * in_cs);
+      px[0] = v.x; px[1] = v.y; px[2] = v.z;
+    }
+    const float* wt = ws + tap * 3 * COUT;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int c = 0; c < COUT; c += 4) {
+        const float4 k = *reinterpret_cast<const float4*>(wt + ci * COUT + c);
+        acc[c] = fmaf(px[ci], k.x, acc[c]); acc[c + 1] = fmaf(px[ci], k.y, acc[c + 1]);
+        acc[c + 2] = fmaf(px[ci], k.z, acc[c + 2]); acc[c + 3] = fmaf(px[ci], k.w, acc[c + 3]);
+      }
+  }
+  T* op = out + (size_t)gp * out_cs + out_coff;
+#pragma unroll
+  for (int c = 0; c < COUT; c += 4) {
+    const float4 b = *reinterpret_cast<const float4*>(bias + c);
+    st4<T>(op + c, make_float4(act_fn(acc[c] + b.x, act), act_fn(acc[c + 1] + b.y, act), act_fn(acc[c + 2] + b.z, act), act_fn(acc[c + 3] + b.w, act)));
+  }
 }
 
 // ---- C2PSA attention ----------------------------------------------------------------------------------------------
@@ -226,6 +295,32 @@ inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1)
 
 }  // namespace
 
+bool conv_direct_eligible(const ConvOp& op) {
+  const PackedConv& pc = *op.pc;
+  return pc.w_direct.p != nullptr && pc.k == 3 && !op.up && !op.has_res1 && !op.has_res2 && op.out.dt == pc.dt && op.in.coff == 0 &&
+         (pc.cout == 16 || pc.cout == 32 || pc.cout == 64) && op.out.cs % 4 == 0 && op.out.coff % 4 == 0 && op.in.cs == (pc.dt == F16 ? 8 : 4);
+}
+
+template <typename T, int COUT>
+static void launch_direct_t(const ConvOp& op, hipStream_t st) {
+  const PackedConv& pc = *op.pc;
+  const long long total = op.out.lvl->total_px;
+  hipLaunchKernelGGL((conv3x3_c3_direct_kernel<T, COUT>), dim3(blocks_for(total, 256)), dim3(256), 0, st, (const T*)op.in.ptr, op.in.cs,
+                     (T*)op.out.ptr, op.out.cs, op.out.coff, pc.w_direct.as<float>(), pc.bias.as<float>(), op.stride, op.act,
+                     op.in.lvl->d_tab.as<int4>(), op.out.lvl->d_tab.as<int4>(), op.out.lvl->n, total);
+}
+
+void launch_conv_direct(const ConvOp& op, hipStream_t st) {
+  const PackedConv& pc = *op.pc;
+  FFP_CHECK(conv_direct_eligible(op), FFP_ERR_ARG, "conv %s: not eligible for the direct kernel", pc.name.c_str());
+  if (pc.dt == F32) {
+    if (pc.cout == 16) launch_direct_t<float, 16>(op, st); else if (pc.cout == 32) launch_direct_t<float, 32>(op, st); else launch_direct_t<float, 64>(op, st);
+  } else {
+    if (pc.cout == 16) launch_direct_t<_Float16, 16>(op, st); else if (pc.cout == 32) launch_direct_t<_Float16, 32>(op, st); else launch_direct_t<_Float16, 64>(op, st);
+  }
+  FFP_HIP(hipGetLastError());
+}
+
 void launch_dwconv(const DwConvOp& op, hipStream_t st) {
   const PackedConv& pc = *op.pc;
   FFP_CHECK(pc.depthwise() && pc.k == 3, FFP_ERR_ARG, "dwconv %s: expects depthwise 3x3", pc.name.c_str());
@@ -233,7 +328,10 @@ void launch_dwconv(const DwConvOp& op, hipStream_t st) {
   FFP_CHECK(op.out.C == C && op.in.lvl == op.out.lvl, FFP_ERR_ARG, "dwconv %s: view mismatch", pc.name.c_str());
   const int grp = op.grp > 0 ? op.grp : C;
   const int gstride = op.grp > 0 ? op.grp_stride : C;
-  const long long total = op.out.lvl->total_px * C;
+  FFP_CHECK(C % 4 == 0 && grp % 4 == 0 && op.in.cs % 4 == 0 && (op.in.coff + op.grp_off) % 4 == 0 && gstride % 4 == 0 && op.out.cs % 4 == 0 &&
+                op.out.coff % 4 == 0 && (!op.has_res || (op.res.cs % 4 == 0 && op.res.coff % 4 == 0)),
+            FFP_ERR_ARG, "dwconv %s: channel counts/offsets must be multiples of 4", pc.name.c_str());
+  const long long total = op.out.lvl->total_px * (C / 4);
   const int4* tab = op.out.lvl->d_tab.as<int4>();
   const unsigned nb = blocks_for(total, 256);
   if (op.in.dt == F32)
@@ -252,7 +350,9 @@ void launch_dwconv(const DwConvOp& op, hipStream_t st) {
 void launch_sppf_pool(const TView& in, const TView& y1, const TView& y2, const TView& y3, hipStream_t st) {
   FFP_CHECK(y1.ptr == y2.ptr && y2.ptr == y3.ptr && y1.cs == y2.cs && y2.cs == y3.cs, FFP_ERR_ARG, "sppf: outputs must be slices of one buffer");
   const int C = in.C;
-  const long long total = in.lvl->total_px * C;
+  FFP_CHECK(C % 4 == 0 && in.cs % 4 == 0 && in.coff % 4 == 0 && y1.cs % 4 == 0 && y1.coff % 4 == 0 && y2.coff % 4 == 0 && y3.coff % 4 == 0,
+            FFP_ERR_ARG, "sppf: channel counts/offsets must be multiples of 4");
+  const long long total = in.lvl->total_px * (C / 4);
   const unsigned nb = blocks_for(total, 256);
   const int4* tab = in.lvl->d_tab.as<int4>();
   if (in.dt == F32)
@@ -267,16 +367,15 @@ void launch_sppf_pool(const TView& in, const TView& y1, const TView& y2, const T
 
 void launch_upsample2x(const TView& in, const TView& out, hipStream_t st) {
   FFP_CHECK(in.C == out.C && in.dt == out.dt && in.lvl->n == out.lvl->n, FFP_ERR_ARG, "upsample: view mismatch");
-  const long long total = out.lvl->total_px * in.C;
+  const int es = dsize(in.dt);
+  FFP_CHECK((in.C * es) % 16 == 0 && (in.cs * es) % 16 == 0 && (in.coff * es) % 16 == 0 && (out.cs * es) % 16 == 0 && (out.coff * es) % 16 == 0,
+            FFP_ERR_ARG, "upsample: views must be 16-byte aligned");
+  const int nvec = in.C * es / 16;
+  const long long total = out.lvl->total_px * nvec;
   const unsigned nb = blocks_for(total, 256);
-  if (in.dt == F32)
-    hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)in.ptr, in.cs, in.coff,
-                       in.lvl->d_tab.as<int4>(), (float*)out.ptr, out.cs, out.coff, out.lvl->d_tab.as<int4>(), out.lvl->n, in.C,
-                       out.lvl->total_px);
-  else
-    hipLaunchKernelGGL(upsample2x_kernel<_Float16>, dim3(nb), dim3(256), 0, st, (const _Float16*)in.ptr, in.cs, in.coff,
-                       in.lvl->d_tab.as<int4>(), (_Float16*)out.ptr, out.cs, out.coff, out.lvl->d_tab.as<int4>(), out.lvl->n,
-                       in.C, out.lvl->total_px);
+  hipLaunchKernelGGL(upsample2x_kernel, dim3(nb), dim3(256), 0, st, (const unsigned char*)in.ptr, in.cs * es, in.coff * es,
+                     in.lvl->d_tab.as<int4>(), (unsigned char*)out.ptr, out.cs * es, out.coff * es, out.lvl->d_tab.as<int4>(), out.lvl->n, nvec,
+                     out.lvl->total_px);
   FFP_HIP(hipGetLastError());
 }
 

@@ -87,6 +87,15 @@ void pack_conv(PackedConv& pc, const std::string& name, const float* w, const fl
     FFP_HIP(hipStreamSynchronize(st));
     return;
   }
+  if (cin_real == 3 && k == 3) {         // image-input convs also get a direct (VALU) form: [tap][ci][cout_pad]
+    std::vector<float> hd((size_t)taps * 3 * cout, 0.f);    // [tap][ci][cout], unpadded (the direct kernel is instantiated per cout)
+    for (int n = 0; n < cout; ++n)
+      for (int c = 0; c < 3; ++c)
+        for (int t = 0; t < taps; ++t) hd[((size_t)t * 3 + c) * cout + n] = w[((size_t)n * cin + c) * taps + t];
+    pc.w_direct.alloc(hd.size() * 4);
+    FFP_HIP(hipMemcpyAsync(pc.w_direct.p, hd.data(), hd.size() * 4, hipMemcpyHostToDevice, st));
+    FFP_HIP(hipStreamSynchronize(st));
+  }
   const int KG = dt == F16 ? 16 : 8;    // input channels per fragment group
   const int EH = KG / 2;                // elements per lane (8 halfs / 4 floats = 16 bytes)
   pc.cin_pad = (cin + KG - 1) / KG * KG;

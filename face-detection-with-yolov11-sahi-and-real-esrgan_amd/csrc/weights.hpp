@@ -32,6 +32,7 @@ struct PackedConv {
   int cin_pad = 0, cout_pad = 0, ncg = 0;
   DType dt = F32;
   DevBuf w, bias;
+  DevBuf w_direct;   // k3 convs with 3 real input channels (stem, conv_first): fp32 [tap][3][cout] for the direct kernel
   bool depthwise() const { return groups > 1; }
 };
 

@@ -203,6 +203,9 @@ int ffp_det_profile_get(ffp_det* d, int i, char* name, int name_cap, double* out
 int ffp_sr_set_profile(ffp_sr* s, int enable);
 int ffp_sr_profile_count(ffp_sr* s, int32_t* out_n);
 int ffp_sr_profile_get(ffp_sr* s, int i, char* name, int name_cap, double* out_flops, float* out_ms, int32_t* out_launches);
+/* per-launch entries of the last profiled call, in launch order: "<variant> <layer name>"; returns FFP_ERR_ARG past the end */
+int ffp_det_profile_detail(ffp_det* d, int i, char* name, int name_cap, double* out_flops, float* out_ms);
+int ffp_sr_profile_detail(ffp_sr* s, int i, char* name, int name_cap, double* out_flops, float* out_ms);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,9 @@ CASES = [
     (1, 16, 16, 8, 16, 3, 1, 1, 0, False),
     (1, 8, 8, 1024, 512, 1, 1, 1, 0, False),
     (1, 16, 16, 768, 256, 1, 1, 1, 0, False),
+    (1, 33, 47, 3, 32, 3, 2, 1, 0, False),      # image-input convs: direct VALU kernel
+    (2, 16, 16, 3, 64, 3, 1, 2, 0, False),
+    (1, 20, 20, 3, 16, 3, 2, 1, 0, False),
 ]
 
 
@@ -57,7 +60,7 @@ CASES = [
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_%dx%d_c%d-%d_k%ds%d_a%d_u%d_r%d" % c)
 def test_conv_dense(gpu_lib, case, half):
     n, h, w, cin, cout, k, stride, act, up, has_res = case
-    if half and cin % 8:
+    if half and cin % 8 and cin != 3:
         pytest.skip("fp16 activations are addressed in 8-channel vectors")
     rng = np.random.default_rng(hash(case) % (2 ** 31))
     x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
