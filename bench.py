@@ -23,7 +23,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+# dense MFMA peaks (/opt/skills/guides/MI355X_MICROARCH.md); f32x3 spends three fp16 MFMAs per algorithmic product
+PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32x3": 2500.0 / 3}
 
 
 def parse():
@@ -37,7 +38,8 @@ def parse():
     ap.add_argument("--overlap", type=float, default=0.2)
     ap.add_argument("--imgsz", type=int, default=512, help="network input size (512 = native tile; 1024 = reference wrapper default)")
     ap.add_argument("--arch", default="s")
-    ap.add_argument("--det-precision", default="f32", choices=["f32", "f16"])
+    ap.add_argument("--det-precision", default="f32x3", choices=["f32", "f32x3", "f16"],
+                    help="f32: exact-fp32 MFMA; f32x3: fp32 storage, fp16 hi/lo split products (fp32-grade); f16: speed mode")
     ap.add_argument("--sr-crops", type=int, default=32, help="crops enhanced per frame (0: config 2, detection only)")
     ap.add_argument("--pp-type", default="GREEDYNMM")
     ap.add_argument("--conf", type=float, default=0.5)
@@ -112,7 +114,7 @@ def main():
     det_w = synth.yolo11_pose_weights(args.arch)
     sr_w = synth.rrdbnet_weights(4, 23) if args.sr_crops > 0 else None
     pipe = pipeline.FramePipeline(det_w, sr_w, cfg, arch=args.arch, device=local_rank,
-                                  det_precision=_lib.PREC_F16 if args.det_precision == "f16" else _lib.PREC_F32, sr_half=True,
+                                  det_precision={"f16": _lib.PREC_F16, "f32x3": _lib.PREC_F32X3, "f32": _lib.PREC_F32}[args.det_precision], sr_half=True,
                                   rank=rank, world=world)
 
     # synthetic frames, resident in HBM before the timed region: `distinct` super-frames of B stacked 4K frames

@@ -16,7 +16,7 @@ from . import weights_io
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libffp.so")
 
-PREC_F32, PREC_F16 = 0, 1
+PREC_F32, PREC_F16, PREC_F32X3 = 0, 1, 2
 CHAN_AS_BGR, CHAN_AS_RGB = 0, 1
 PP_NMS, PP_GREEDYNMM = 0, 1
 METRIC_IOU, METRIC_IOS = 0, 1

@@ -395,11 +395,12 @@ int ffp_op_conv2d(int device, int precision, const float* x, int n, int h, int w
   FFP_HIP(hipSetDevice(device));
   conv_kernels_init();
   const DType T = precision == FFP_PREC_F16 ? F16 : F32;
+  const bool split = precision == FFP_PREC_F32X3;
   hipStream_t st;
   FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   try {
     PackedConv pc;
-    pack_conv(pc, "op", wt, bias, cout, cin, k, groups, T, st);
+    pack_conv(pc, "op", wt, bias, cout, cin, k, groups, T, st, split);
     const int hi = up ? h * 2 : h, wi = up ? w * 2 : w;
     const int ho = (hi + 2 * (k / 2) - k) / stride + 1, wo = (wi + 2 * (k / 2) - k) / stride + 1;
     Level lin, lout;

@@ -11,6 +11,8 @@
 // Workgroup = 256 threads = 4 waves laid out WM x WN; a wave owns MI pixel fragments x NIW 32-channel tiles.
 // blockIdx is remapped so that the n-blocks of one pixel tile and neighbouring tiles share an XCD (L2 reuse of the
 // input tile); the mapping only affects speed.
+#include <type_traits>
+
 #include "ops.hpp"
 
 namespace ffp {
@@ -36,6 +38,17 @@ struct ConvArgs {
   int act, out_f32, up, n_nblk, ncg, ntiles32, vec_ok;
 };
 
+// fp32 storage with operands split into fp16 hi + lo parts: a*b ~= ah*bh + ah*bl + al*bh (three fp16 MFMAs, fp32
+// accumulate; the dropped al*bl term is 2^-22 relative) — fp32-grade products at 3/16 of the exact-fp32 MFMA time.
+struct X3 {};
+
+// arithmetic traits: GT = element type in HBM, KG = input channels per MFMA k-group, LDS_EB = LDS bytes per element,
+// WFRAG = bytes of one packed weight fragment (32 out channels x one k-group)
+template <typename T> struct Ar;
+template <> struct Ar<float> { using GT = float; static constexpr int KG = 8, LDS_EB = 4, WFRAG = 1024; };
+template <> struct Ar<_Float16> { using GT = _Float16; static constexpr int KG = 16, LDS_EB = 2, WFRAG = 1024; };
+template <> struct Ar<X3> { using GT = float; static constexpr int KG = 16, LDS_EB = 4, WFRAG = 2048; };
+
 template <typename T> struct MM;
 template <> struct MM<float> {
   static constexpr int KG = 8;
@@ -52,6 +65,17 @@ template <> struct MM<_Float16> {
     union { uint4 u; f16x8 h; } ua, ub;
     ua.u = a; ub.u = b;
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ua.h, ub.h, acc, 0, 0, 0);
+  }
+};
+
+template <> struct MM<X3> {
+  static constexpr int KG = 16;
+  static __device__ __forceinline__ void mma3(f32x16& acc, const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl) {
+    union { uint4 u; f16x8 h; } uah, ual, ubh, ubl;
+    uah.u = ah; ual.u = al; ubh.u = bh; ubl.u = bl;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ual.h, ubh.h, acc, 0, 0, 0);     // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(uah.h, ubl.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(uah.h, ubh.h, acc, 0, 0, 0);
   }
 };
 
@@ -89,24 +113,27 @@ template <> __device__ __forceinline__ void store4<_Float16>(_Float16* p, const 
 
 // compile-time geometry shared by the kernel and its launcher
 template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int KC> struct Geo {
-  static constexpr int ES = sizeof(T);
-  static constexpr int KG = MM<T>::KG;
+  using GT = typename Ar<T>::GT;
+  static constexpr int ES = sizeof(GT);                      // bytes per element in HBM
+  static constexpr int KG = Ar<T>::KG;
+  static constexpr int WFRAG = Ar<T>::WFRAG;
   static constexpr int KCG = KC / KG;                       // k-groups per chunk
   static constexpr int FR = WM * MI;                        // pixel fragments per workgroup (32 px each)
   static constexpr int TH = FR * 2;                         // output tile rows (16 columns)
   static constexpr int HH = KS == 1 ? 1 : (TH - 1) * STRIDE + KS;
   static constexpr int HW = KS == 1 ? FR * 32 : 15 * STRIDE + KS;
   static constexpr int NPIX = HH * HW;                      // staged input pixels
-  static constexpr int PS = KC * ES + 16;                   // LDS bytes per pixel record (+1 b128 pad against bank conflicts)
-  static constexpr int VPP = KC * ES / 16;                  // 16-byte vectors per pixel per chunk
+  static constexpr int PS = KC * Ar<T>::LDS_EB + 16;        // LDS bytes per pixel record (+1 b128 pad against bank conflicts)
+  static constexpr int VPP = KC * ES / 16;                  // 16-byte global vectors per pixel per chunk
   static constexpr int EPV = 16 / ES;                       // elements per vector
   static constexpr int TAPS = KS * KS;
   static constexpr int NTB = WN * NIW;                      // 32-channel tiles per workgroup
   static constexpr int IN_BYTES = (NPIX * PS + 15) / 16 * 16;
-  static constexpr int W_FRAGS = NTB * TAPS * KCG;          // 1 KiB weight fragments per chunk
-  static constexpr int BUF = IN_BYTES + W_FRAGS * 1024;     // one LDS stage: input tile chunk + its weights
+  static constexpr int W_FRAGS = NTB * TAPS * KCG;          // weight fragments per chunk
+  static constexpr int VPF = WFRAG / 16;                    // 16-byte vectors per weight fragment
+  static constexpr int BUF = IN_BYTES + W_FRAGS * WFRAG;    // one LDS stage: input tile chunk + its weights
   static constexpr int LDS = 2 * BUF;                       // double buffered
-  static constexpr int NVI = NPIX * VPP, NVW = W_FRAGS * 64;
+  static constexpr int NVI = NPIX * VPP, NVW = W_FRAGS * VPF;
   static constexpr int RI = (NVI + 255) / 256, RW = (NVW + 255) / 256;   // prefetch registers (16 B each) per thread
   static_assert(KC % KG == 0 && WM * WN == 4, "geometry");
 };
@@ -115,10 +142,13 @@ template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int K
 // chunk c+1 is fetched global->registers while chunk c is multiplied out of LDS (no global access inside the MFMA
 // loop), then written to the other stage: one barrier per chunk.
 template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int KC>
-__global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
   using G = Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>;
+  using GT = typename G::GT;
+  constexpr bool SPLIT = std::is_same<T, X3>::value;
   constexpr int ES = G::ES, KG = G::KG, KCG = G::KCG, HW = G::HW, NPIX = G::NPIX, PS = G::PS, VPP = G::VPP, EPV = G::EPV;
-  constexpr int TAPS = G::TAPS, NTB = G::NTB, RI = G::RI, RW = G::RW;
+  constexpr int TAPS = G::TAPS, NTB = G::NTB, RI = G::RI, RW = G::RW, WFRAG = G::WFRAG, VPF = G::VPF;
+  constexpr int LKB = KG * Ar<T>::LDS_EB / (SPLIT ? 2 : 1);   // LDS bytes one k-group spans inside the (hi) block of a pixel record
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -184,11 +214,11 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a) {
     const int idx = tid + i * 256;
     wsrc[i] = -1; wkg[i] = 0;
     if (idx < G::NVW) {
-      const int fl = idx >> 6, l = idx & 63;
+      const int fl = idx / VPF, l = idx % VPF;
       const int kg = fl % KCG, tap = (fl / KCG) % TAPS, ntl = fl / (KCG * TAPS);
       const int nt = min(nblk * NTB + ntl, a.ntiles32 - 1);
       wkg[i] = kg;
-      wsrc[i] = ((long long)(nt * TAPS + tap) * a.ncg) * 1024 + l * 16;
+      wsrc[i] = ((long long)(nt * TAPS + tap) * a.ncg) * WFRAG + l * 16;
     }
   }
 
@@ -205,7 +235,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (wsrc[i] >= 0 && cg0 + wkg[i] < a.ncg) v = *reinterpret_cast<const uint4*>(wb + wsrc[i] + (long long)(cg0 + wkg[i]) * 1024);
+      if (wsrc[i] >= 0 && cg0 + wkg[i] < a.ncg) v = *reinterpret_cast<const uint4*>(wb + wsrc[i] + (long long)(cg0 + wkg[i]) * WFRAG);
       rw[i] = v;
     }
   };
@@ -213,7 +243,19 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
       const int idx = tid + i * 256;
-      if (idx < G::NVI) *reinterpret_cast<uint4*>(buf + (idx / VPP) * PS + (idx % VPP) * 16) = ri[i];
+      if (idx < G::NVI) {
+        if (SPLIT) {   // 4 floats -> 4 fp16 hi parts + 4 fp16 residuals, stored in the hi / lo halves of the pixel record
+          const float f[4] = {__uint_as_float(ri[i].x), __uint_as_float(ri[i].y), __uint_as_float(ri[i].z), __uint_as_float(ri[i].w)};
+          union { uint2 u; _Float16 h[4]; } hi, lo;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { hi.h[q] = (_Float16)f[q]; lo.h[q] = (_Float16)(f[q] - (float)hi.h[q]); }
+          unsigned char* rec = buf + (idx / VPP) * PS + (idx % VPP) * 8;
+          *reinterpret_cast<uint2*>(rec) = hi.u;
+          *reinterpret_cast<uint2*>(rec + KC * 2) = lo.u;
+        } else {
+          *reinterpret_cast<uint4*>(buf + (idx / VPP) * PS + (idx % VPP) * 16) = ri[i];
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
@@ -238,7 +280,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a) {
     const bool more = c0 + KC < a.cin;
     if (more) fetch(c0 + KC);                              // in flight while this chunk is multiplied
     const unsigned char* sb = smem + cur * G::BUF;
-    const unsigned char* sw = sb + G::IN_BYTES + ((wn * NIW) * TAPS * KCG) * 1024 + lane * 16;
+    const unsigned char* sw = sb + G::IN_BYTES + ((wn * NIW) * TAPS * KCG) * WFRAG + lane * 16;
     const int kmax = min(KC, a.cin_pad - c0) / KG;
 #pragma unroll
     for (int ks = 0; ks < KCG; ++ks) {
@@ -246,15 +288,32 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
           const int ky = tap / KS, kx = tap % KS;
-          uint4 bf[MI];
+          if constexpr (SPLIT) {
+            uint4 bh[MI], bl[MI];
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-            bf[mi] = *reinterpret_cast<const uint4*>(sb + boff[mi] + (ky * HW + kx) * PS + ks * (KG * ES));
+            for (int mi = 0; mi < MI; ++mi) {
+              const unsigned char* bp = sb + boff[mi] + (ky * HW + kx) * PS + ks * LKB;
+              bh[mi] = *reinterpret_cast<const uint4*>(bp);
+              bl[mi] = *reinterpret_cast<const uint4*>(bp + KC * 2);
+            }
 #pragma unroll
-          for (int ni = 0; ni < NIW; ++ni) {
-            const uint4 af = *reinterpret_cast<const uint4*>(sw + ((ni * TAPS + tap) * KCG + ks) * 1024);
+            for (int ni = 0; ni < NIW; ++ni) {
+              const unsigned char* ap = sw + ((ni * TAPS + tap) * KCG + ks) * WFRAG;
+              const uint4 ah = *reinterpret_cast<const uint4*>(ap), al = *reinterpret_cast<const uint4*>(ap + 1024);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) MM<T>::mma(acc[ni][mi], af, bf[mi]);
+              for (int mi = 0; mi < MI; ++mi) MM<X3>::mma3(acc[ni][mi], ah, al, bh[mi], bl[mi]);
+            }
+          } else {
+            uint4 bf[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+              bf[mi] = *reinterpret_cast<const uint4*>(sb + boff[mi] + (ky * HW + kx) * PS + ks * LKB);
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni) {
+              const uint4 af = *reinterpret_cast<const uint4*>(sw + ((ni * TAPS + tap) * KCG + ks) * WFRAG);
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi) MM<T>::mma(acc[ni][mi], af, bf[mi]);
+            }
           }
         }
       }
@@ -297,17 +356,17 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a) {
         for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], a.act);
         const bool vec = a.vec_ok && ch + 3 < a.cout;
         if (a.res1) {
-          const T* rp = reinterpret_cast<const T*>(a.res1) + (size_t)gp * a.r1_cs + a.r1_coff + ch;
+          const GT* rp = reinterpret_cast<const GT*>(a.res1) + (size_t)gp * a.r1_cs + a.r1_coff + ch;
           float r[4] = {0.f, 0.f, 0.f, 0.f};
-          if (vec) load4<T>(rp, r);
+          if (vec) load4<GT>(rp, r);
           else for (int j = 0; j < 4; ++j) if (ch + j < a.cout) r[j] = (float)rp[j];
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = v[j] * a.s1 + r[j];
         }
         if (a.res2) {
-          const T* rp = reinterpret_cast<const T*>(a.res2) + (size_t)gp * a.r2_cs + a.r2_coff + ch;
+          const GT* rp = reinterpret_cast<const GT*>(a.res2) + (size_t)gp * a.r2_cs + a.r2_coff + ch;
           float r[4] = {0.f, 0.f, 0.f, 0.f};
-          if (vec) load4<T>(rp, r);
+          if (vec) load4<GT>(rp, r);
           else for (int j = 0; j < 4; ++j) if (ch + j < a.cout) r[j] = (float)rp[j];
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = v[j] * a.s2 + r[j];
@@ -318,9 +377,9 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a) {
           if (vec) store4<float>(op, v);
           else for (int j = 0; j < 4; ++j) if (ch + j < a.cout) op[j] = v[j];
         } else {
-          T* op = reinterpret_cast<T*>(a.out) + oidx;
-          if (vec) store4<T>(op, v);
-          else for (int j = 0; j < 4; ++j) if (ch + j < a.cout) op[j] = (T)v[j];
+          GT* op = reinterpret_cast<GT*>(a.out) + oidx;
+          if (vec) store4<GT>(op, v);
+          else for (int j = 0; j < 4; ++j) if (ch + j < a.cout) op[j] = (GT)v[j];
         }
       }
     }
@@ -333,36 +392,41 @@ namespace {
 template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int KC> struct Cfg {
   using G = Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>;
   static constexpr int LDS = G::LDS;
+  static constexpr bool OK = LDS <= 160 * 1024;            // shapes that do not fit the LDS are simply not offered
   static constexpr int BLOCK_PX = G::FR * 32;
   static constexpr int BLOCK_N = G::NTB * 32;
-  static_assert(LDS <= 160 * 1024, "LDS budget");
-  static auto kernel() { return &conv_mfma_kernel<T, KS, STRIDE, WM, WN, MI, NIW, KC>; }
   static void init() {
-    FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel()), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    if constexpr (OK)
+      FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, KS, STRIDE, WM, WN, MI, NIW, KC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   }
   static void launch(ConvArgs& a, Level* out_lvl, hipStream_t st) {
-    int n_tiles;
-    if (KS == 1) {
-      n_tiles = (int)((a.total_px + BLOCK_PX - 1) / BLOCK_PX);
+    if constexpr (OK) {
+      int n_tiles;
+      if (KS == 1) {
+        n_tiles = (int)((a.total_px + BLOCK_PX - 1) / BLOCK_PX);
+      } else {
+        a.tiles = out_lvl->tile_table(G::TH, &n_tiles, st);
+      }
+      a.n_nblk = (a.ntiles32 * 32 + BLOCK_N - 1) / BLOCK_N;
+      const int grid = n_tiles * a.n_nblk;
+      if (grid == 0) return;
+      hipLaunchKernelGGL((conv_mfma_kernel<T, KS, STRIDE, WM, WN, MI, NIW, KC>), dim3(grid), dim3(256), LDS, st, a);
     } else {
-      a.tiles = out_lvl->tile_table(G::TH, &n_tiles, st);
+      fail(FFP_ERR_STATE, "conv: shape does not fit the LDS");
     }
-    a.n_nblk = (a.ntiles32 * 32 + BLOCK_N - 1) / BLOCK_N;
-    const int grid = n_tiles * a.n_nblk;
-    if (grid == 0) return;
-    hipLaunchKernelGGL(kernel(), dim3(grid), dim3(256), LDS, st, a);
   }
 };
 
 // chunk sizes (input channels per LDS stage), chosen so that 2 x (input tile + weight fragments) fits the 160 KiB LDS
 //                                   shape: 0 wide, 1 narrow2, 2 narrow1
 template <typename T, int KS, int STRIDE, int SHAPE> struct KCof;
-template <> struct KCof<float, 1, 1, 0> { static constexpr int v = 32; };
-template <> struct KCof<float, 1, 1, 1> { static constexpr int v = 32; };
-template <> struct KCof<float, 1, 1, 2> { static constexpr int v = 64; };
+template <> struct KCof<float, 1, 1, 0> { static constexpr int v = 16; };
+template <> struct KCof<float, 1, 1, 1> { static constexpr int v = 16; };
+template <> struct KCof<float, 1, 1, 2> { static constexpr int v = 16; };
 template <> struct KCof<float, 3, 1, 0> { static constexpr int v = 8; };
-template <> struct KCof<float, 3, 1, 1> { static constexpr int v = 16; };
-template <> struct KCof<float, 3, 1, 2> { static constexpr int v = 16; };
+template <> struct KCof<float, 3, 1, 1> { static constexpr int v = 8; };
+template <> struct KCof<float, 3, 1, 2> { static constexpr int v = 8; };
 template <> struct KCof<float, 3, 2, 0> { static constexpr int v = 8; };
 template <> struct KCof<float, 3, 2, 1> { static constexpr int v = 16; };
 template <> struct KCof<float, 3, 2, 2> { static constexpr int v = 16; };
@@ -379,6 +443,8 @@ template <> struct KCof<_Float16, 3, 2, 2> { static constexpr int v = 32; };
 // Shape selection: six workgroup shapes per (dtype, k, stride) — {wide 128ch, narrow2 64ch, narrow1 32ch} x {full, half
 // pixel tile}. The largest block (most operand reuse) that still yields >= 2 workgroups per CU wins; layers with few
 // pixels (stride-32 maps, face crops) fall through to smaller blocks so that the whole chip is busy.
+template <int KS, int STRIDE, int SHAPE> struct KCof<X3, KS, STRIDE, SHAPE> { static constexpr int v = 16; };
+
 template <typename T, int KS, int STRIDE> struct Family {
   static constexpr int MIW = STRIDE == 2 ? 2 : 4;   // wide: 2x2 waves
   static constexpr int MIN = STRIDE == 2 ? 1 : 2;   // narrow: 4x1 waves
@@ -407,12 +473,14 @@ template <typename T, int KS, int STRIDE> struct Family {
       if (!valid || best_n >= ENOUGH) return;
       if (n >= ENOUGH || n > best_n) { best = id; best_n = n; }
     };
-    consider(0, wgs<Wide>(a, out_lvl), a.ntiles32 >= 3);
-    consider(1, wgs<WideH>(a, out_lvl), a.ntiles32 >= 3);
-    consider(2, wgs<Narrow2>(a, out_lvl), a.ntiles32 >= 2);
-    if (HAS_NH) consider(3, wgs<Narrow2H>(a, out_lvl), a.ntiles32 >= 2);
-    consider(4, wgs<Narrow1>(a, out_lvl), true);
-    if (HAS_NH) consider(5, wgs<Narrow1H>(a, out_lvl), true);
+    // 3x3: a 128-channel block needs 36 KiB of weights per stage -> one workgroup per CU; 64-channel blocks keep two resident
+    consider(0, wgs<Wide>(a, out_lvl), Wide::OK && a.ntiles32 >= 3 && (KS == 1 || STRIDE == 2));
+    consider(1, wgs<WideH>(a, out_lvl), WideH::OK && a.ntiles32 >= 3 && (KS == 1 || STRIDE == 2));
+    consider(2, wgs<Narrow2>(a, out_lvl), Narrow2::OK && a.ntiles32 >= 2);
+    if (HAS_NH) consider(3, wgs<Narrow2H>(a, out_lvl), Narrow2H::OK && a.ntiles32 >= 2);
+    consider(4, wgs<Narrow1>(a, out_lvl), Narrow1::OK);
+    if (HAS_NH) consider(5, wgs<Narrow1H>(a, out_lvl), Narrow1H::OK);
+    if (best < 0) fail(FFP_ERR_STATE, "conv: no workgroup shape fits");
     return best;
   }
   static void launch(ConvArgs& a, Level* out_lvl, hipStream_t st) {
@@ -450,6 +518,7 @@ void conv_kernels_init() {
   if (done) return;
   Family<float, 1, 1>::init(); Family<float, 3, 1>::init(); Family<float, 3, 2>::init();
   Family<_Float16, 1, 1>::init(); Family<_Float16, 3, 1>::init(); Family<_Float16, 3, 2>::init();
+  Family<X3, 1, 1>::init(); Family<X3, 3, 1>::init(); Family<X3, 3, 2>::init();
   done = true;
 }
 
@@ -495,8 +564,9 @@ void launch_conv(const ConvOp& op, hipStream_t st) {
   const PackedConv& pc = *op.pc;
   if (conv_direct_eligible(op)) { launch_conv_direct(op, st); return; }
   ConvArgs a = make_args(op);
-  if (pc.dt == F32) launch_t<float>(a, pc.k, op.stride, op.out.lvl, st);
-  else launch_t<_Float16>(a, pc.k, op.stride, op.out.lvl, st);
+  if (pc.dt == F16) launch_t<_Float16>(a, pc.k, op.stride, op.out.lvl, st);
+  else if (pc.split) launch_t<X3>(a, pc.k, op.stride, op.out.lvl, st);
+  else launch_t<float>(a, pc.k, op.stride, op.out.lvl, st);
   FFP_HIP(hipGetLastError());
 }
 
@@ -504,9 +574,10 @@ std::string conv_variant(const ConvOp& op) {
   const PackedConv& pc = *op.pc;
   if (conv_direct_eligible(op)) return std::string(pc.dt == F32 ? "f32" : "f16") + "_k3_direct";
   const ConvArgs a = make_args(op);
-  const int shape = pc.dt == F32 ? choose_t<float>(a, pc.k, op.stride, op.out.lvl) : choose_t<_Float16>(a, pc.k, op.stride, op.out.lvl);
+  const int shape = pc.dt == F16 ? choose_t<_Float16>(a, pc.k, op.stride, op.out.lvl)
+                    : pc.split ? choose_t<X3>(a, pc.k, op.stride, op.out.lvl) : choose_t<float>(a, pc.k, op.stride, op.out.lvl);
   char buf[64];
-  snprintf(buf, sizeof(buf), "%s_k%ds%d_%s", pc.dt == F32 ? "f32" : "f16", pc.k, op.stride, kShapeNames[shape < 0 ? 4 : shape]);
+  snprintf(buf, sizeof(buf), "%s_k%ds%d_%s", pc.dt == F16 ? "f16" : pc.split ? "f32x3" : "f32", pc.k, op.stride, kShapeNames[shape < 0 ? 4 : shape]);
   return buf;
 }
 

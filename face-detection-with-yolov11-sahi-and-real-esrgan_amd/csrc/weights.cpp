@@ -53,8 +53,10 @@ static inline uint16_t f32_to_f16_bits(float f) {
 }
 
 void pack_conv(PackedConv& pc, const std::string& name, const float* w, const float* b, int cout, int cin, int k,
-               int groups, DType dt, hipStream_t st) {
+               int groups, DType dt, hipStream_t st, bool split) {
   FFP_CHECK(k == 1 || k == 3, FFP_ERR_ARG, "conv %s: kernel size %d unsupported", name.c_str(), k);
+  FFP_CHECK(!split || dt == F32, FFP_ERR_ARG, "conv %s: split packing is an fp32-storage mode", name.c_str());
+  pc.split = split && groups == 1;
   FFP_CHECK(groups == 1 || (groups == cin && cin == cout), FFP_ERR_ARG, "conv %s: only dense or depthwise groups", name.c_str());
   const int taps = k * k;
   std::vector<float> wpad;
@@ -96,23 +98,29 @@ void pack_conv(PackedConv& pc, const std::string& name, const float* w, const fl
     FFP_HIP(hipMemcpyAsync(pc.w_direct.p, hd.data(), hd.size() * 4, hipMemcpyHostToDevice, st));
     FFP_HIP(hipStreamSynchronize(st));
   }
-  const int KG = dt == F16 ? 16 : 8;    // input channels per fragment group
+  const int KG = (dt == F16 || pc.split) ? 16 : 8;    // input channels per fragment group
   const int EH = KG / 2;                // elements per lane (8 halfs / 4 floats = 16 bytes)
   pc.cin_pad = (cin + KG - 1) / KG * KG;
   pc.ncg = pc.cin_pad / KG;
   const int ntile = pc.cout_pad / 32;
   const size_t nfrag = (size_t)ntile * taps * pc.ncg;
-  std::vector<uint8_t> hw(nfrag * 1024, 0);
+  const size_t fbytes = pc.split ? 2048 : 1024;
+  std::vector<uint8_t> hw(nfrag * fbytes, 0);
   for (int nt = 0; nt < ntile; ++nt)
     for (int t = 0; t < taps; ++t)
       for (int cg = 0; cg < pc.ncg; ++cg) {
-        uint8_t* frag = hw.data() + (((size_t)nt * taps + t) * pc.ncg + cg) * 1024;
+        uint8_t* frag = hw.data() + (((size_t)nt * taps + t) * pc.ncg + cg) * fbytes;
         for (int l = 0; l < 64; ++l) {
           const int n = nt * 32 + (l & 31);
           for (int j = 0; j < EH; ++j) {
             const int c = cg * KG + EH * (l >> 5) + j;
             float v = (n < cout && c < cin) ? w[((size_t)n * cin + c) * taps + t] : 0.f;
-            if (dt == F16) {
+            if (pc.split) {          // hi = fp16(v), lo = fp16(v - hi): hi fragment then lo fragment
+              const _Float16 hi = (_Float16)v;
+              const _Float16 lo = (_Float16)(v - (float)hi);
+              std::memcpy(frag + l * 16 + j * 2, &hi, 2);
+              std::memcpy(frag + 1024 + l * 16 + j * 2, &lo, 2);
+            } else if (dt == F16) {
               uint16_t hbits = f32_to_f16_bits(v);
               std::memcpy(frag + l * 16 + j * 2, &hbits, 2);
             } else {
@@ -127,7 +135,7 @@ void pack_conv(PackedConv& pc, const std::string& name, const float* w, const fl
 }
 
 void pack_conv(PackedConv& pc, const WeightFile& wf, const std::string& name, int k, int groups, DType dt,
-               hipStream_t st) {
+               hipStream_t st, bool split) {
   const HostTensor& w = wf.get(name + ".weight");
   const HostTensor& b = wf.get(name + ".bias");
   FFP_CHECK(w.dims.size() == 4 && w.dims[2] == k && w.dims[3] == k, FFP_ERR_WEIGHTS, "%s.weight: expected (co,ci,%d,%d)", name.c_str(), k, k);
@@ -135,7 +143,7 @@ void pack_conv(PackedConv& pc, const WeightFile& wf, const std::string& name, in
   const int cin = w.dims[1] * groups;
   FFP_CHECK(groups == 1 || w.dims[1] == 1, FFP_ERR_WEIGHTS, "%s.weight: depthwise expects (c,1,k,k)", name.c_str());
   FFP_CHECK((int)b.numel() == cout, FFP_ERR_WEIGHTS, "%s.bias: expected %d values", name.c_str(), cout);
-  pack_conv(pc, name, w.data, b.data, cout, cin, k, groups, dt, st);
+  pack_conv(pc, name, w.data, b.data, cout, cin, k, groups, dt, st, split);
 }
 
 }  // namespace ffp

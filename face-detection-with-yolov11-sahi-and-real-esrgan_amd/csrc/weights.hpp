@@ -31,6 +31,7 @@ struct PackedConv {
   int cin_real = 0;                            // channels that carry weights (FLOP accounting)
   int cin_pad = 0, cout_pad = 0, ncg = 0;
   DType dt = F32;
+  bool split = false;   // dt == F32 only: fragments hold fp16 hi + fp16 lo parts (2 KiB each, k-group = 16) for the X3 kernels
   DevBuf w, bias;
   DevBuf w_direct;   // k3 convs with 3 real input channels (stem, conv_first): fp32 [tap][3][cout] for the direct kernel
   bool depthwise() const { return groups > 1; }
@@ -38,8 +39,8 @@ struct PackedConv {
 
 // w: (cout, cin/groups, k, k) fp32 OIHW, b: (cout) or null (zeros)
 void pack_conv(PackedConv& pc, const std::string& name, const float* w, const float* b, int cout, int cin, int k,
-               int groups, DType dt, hipStream_t st);
+               int groups, DType dt, hipStream_t st, bool split = false);
 void pack_conv(PackedConv& pc, const WeightFile& wf, const std::string& name, int k, int groups, DType dt,
-               hipStream_t st);
+               hipStream_t st, bool split = false);
 
 }  // namespace ffp

@@ -30,11 +30,12 @@ void letterbox_geometry(int h, int w, int imgsz, int32_t* o) {
 DetEngine::DetEngine(const void* weights, size_t nbytes, int arch, int nc, int nkpt, int device, int precision) {
   FFP_CHECK(arch == 'n' || arch == 's', FFP_ERR_ARG, "arch must be 'n' or 's'");
   FFP_CHECK(nc >= 1 && nc <= 256 && nkpt >= 0 && nkpt <= 32, FFP_ERR_ARG, "nc/nkpt out of range");
-  FFP_CHECK(precision == FFP_PREC_F32 || precision == FFP_PREC_F16, FFP_ERR_ARG, "precision");
+  FFP_CHECK(precision == FFP_PREC_F32 || precision == FFP_PREC_F16 || precision == FFP_PREC_F32X3, FFP_ERR_ARG, "precision");
   int ndev = 0;
   FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0, FFP_ERR_HIP, "no HIP device available (the detector has no CPU path)");
   FFP_CHECK(device >= 0 && device < ndev, FFP_ERR_ARG, "device %d of %d", device, ndev);
   device_ = device; nc_ = nc; nkpt_ = nkpt; scale_ = (char)arch; dt_ = precision == FFP_PREC_F16 ? F16 : F32;
+  split_ = precision == FFP_PREC_F32X3;
   FFP_HIP(hipSetDevice(device_));
   FFP_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
   for (auto& e : ev_) FFP_HIP(hipEventCreate(&e));
@@ -49,7 +50,7 @@ DetEngine::DetEngine(const void* weights, size_t nbytes, int arch, int nc, int n
     FFP_CHECK(w.dims.size() == 4 && w.dims[2] == w.dims[3], FFP_ERR_WEIGHTS, "%s: not a conv weight", nm.c_str());
     const int k = w.dims[2];
     const int groups = (w.dims[1] == 1 && w.dims[0] > 1 && k == 3) ? w.dims[0] : 1;
-    pack_conv(convs_[base], wf, base, k, groups, dt_, st_);   // input channels are zero-padded to a 16-byte multiple
+    pack_conv(convs_[base], wf, base, k, groups, dt_, st_, split_);   // input channels are zero-padded to a 16-byte multiple
   }
   FFP_CHECK(convs_.count("model.0.conv") && convs_.count("model.23.cv2.0.2"), FFP_ERR_WEIGHTS,
             "container does not hold YOLO11-pose tensors");

@@ -64,6 +64,7 @@ class DetEngine {
   int device_ = 0, nc_ = 1, nkpt_ = 5;
   char scale_ = 's';
   DType dt_ = F32;
+  bool split_ = false;
   hipStream_t st_ = nullptr;
 };
 

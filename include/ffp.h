@@ -32,6 +32,8 @@ extern "C" {
 /* arithmetic type of the convolution path */
 #define FFP_PREC_F32 0 /* fp32 activations, v_mfma_f32_32x32x2_f32 (exact-f32 parity mode) */
 #define FFP_PREC_F16 1 /* fp16 activations, v_mfma_f32_32x32x16_f16, fp32 accumulate */
+#define FFP_PREC_F32X3 2 /* fp32 activations; each product computed as fp16 hi/lo split, 3 fp16 MFMAs (~2^-21 relative),
+                            fp32 accumulate: fp32-grade results at ~5x the exact-fp32 MFMA rate */
 
 /* how a caller's HxWx3 uint8 array maps to network channels.
  * AS_BGR reproduces Ultralytics' ndarray path (network channel 0 = array[...,2]) which is what the reference gets,

@@ -56,6 +56,23 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_%dx%d_c%d-%d_k%ds%d_a%d_u%d_r%d" % c)
+def test_conv_dense_f32x3(gpu_lib, case):
+    """fp32 storage, fp16 hi/lo split products (3 MFMAs): fp32-grade. Tolerance 1e-5 relative to the output scale
+    (vs 2e-5 for the exact-fp32 kernel, whose only noise is summation order)."""
+    n, h, w, cin, cout, k, stride, act, up, has_res = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, cin, k, k), dtype=np.float32) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout, dtype=np.float32) * 0.1
+    hi, wi = (h * 2, w * 2) if up else (h, w)
+    ho, wo = (hi + 2 * (k // 2) - k) // stride + 1, (wi + 2 * (k // 2) - k) // stride + 1
+    res = rng.standard_normal((n, ho, wo, cout), dtype=np.float32) if has_res else None
+    y = gpu_lib.op_conv2d(x, wt, b, stride=stride, act=act, up=bool(up), res=res, res_scale=0.2 if has_res else 1.0, precision=gpu_lib.PREC_F32X3)
+    ref = ref_conv(x, wt, b, stride, 1, act, up, res, 0.2, False)
+    np.testing.assert_allclose(y, ref, rtol=3e-5, atol=3e-5)
+
+
 @pytest.mark.parametrize("half", [False, True], ids=["f32", "f16"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_%dx%d_c%d-%d_k%ds%d_a%d_u%d_r%d" % c)
 def test_conv_dense(gpu_lib, case, half):

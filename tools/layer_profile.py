@@ -9,7 +9,7 @@ import torch
 H, W = 2160, 3840
 cfg = pipeline.PipeConfig()
 pipe = pipeline.FramePipeline(synth.yolo11_pose_weights("s"), synth.rrdbnet_weights(4, 23), cfg, arch="s",
-                              det_precision=_lib.PREC_F16 if "--f16" in sys.argv else _lib.PREC_F32)
+                              det_precision=_lib.PREC_F16 if "--f16" in sys.argv else _lib.PREC_F32X3 if "--x3" in sys.argv else _lib.PREC_F32)
 frame = torch.from_numpy(synth.synthetic_frame(H, W, seed=0)).cuda()
 sizes = pipeline.sr_crop_sizes(32, 0)
 boxes = pipeline.crop_boxes_for_sr(np.zeros((0, 21), np.float32), H, W, 32, sizes, 0)
