@@ -103,10 +103,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    # FFP_BENCH_BACKEND=gloo FFP_BENCH_ONE_DEVICE=1 rehearses the N>1 code path with several ranks on ONE GPU (no RCCL peers)
+    backend = os.environ.get("FFP_BENCH_BACKEND", "nccl")
+    if os.environ.get("FFP_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     H, W, B = args.height, args.width, world
     cfg = pipeline.PipeConfig(slice_h=args.slice, slice_w=args.slice, overlap=args.overlap, imgsz=args.imgsz, conf=args.conf,
@@ -130,12 +137,19 @@ def main():
     host_sr = torch.empty((max(sr_bytes, 16),), dtype=torch.uint8).pin_memory()
     state = {}
 
+    pending = {}     # super-resolution of the previous frame still running on the enhancer's stream
+
+    def drain_sr():
+        if pending:
+            pipe.wait_sr()
+            out = pending.pop("out")
+            host_sr[:out.numel()].copy_(out)                       # enhanced crops -> host
+
     def step(i, profile=False):
+        """Frame i: detect + merge (detector stream) while frame i-1's crops are still being enhanced (enhancer stream)."""
         sf = supers[i % len(supers)]
         if profile:
             pipe.det.set_profile(True)
-            if pipe.sr is not None:
-                pipe.sr.set_profile(True)
         dets, counts, _ = pipe.detect(sf, H, W, B)
         for f in range(B):
             if f % world != rank:
@@ -149,10 +163,14 @@ def main():
             if args.sr_crops > 0:
                 boxes = pipeline.crop_boxes_for_sr(rows, H, W, args.sr_crops, sizes, seed=i)
                 state["boxes"] = boxes
-                out, offs = pipe.enhance_crops(sf[f * H:(f + 1) * H], H, W, boxes)
-                host_sr[:out.numel()].copy_(out)                   # enhanced crops -> host
-        torch.cuda.synchronize(dev)
+                drain_sr()
+                if profile:
+                    pipe.sr.set_profile(True)
+                out, offs = pipe.enhance_crops(sf[f * H:(f + 1) * H], H, W, boxes, wait=False, slot=i & 1)
+                pending["out"] = out
         if profile:
+            drain_sr()
+            torch.cuda.synchronize(dev)
             pipe.det.set_profile(False)
             if pipe.sr is not None:
                 pipe.sr.set_profile(False)
@@ -165,14 +183,16 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    drain_sr()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, profile=(i == args.steps - 1))      # the last timed step also brackets every conv launch with HIP events
+    drain_sr()                                      # the last frame's crops are part of the timed work
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -331,12 +331,13 @@ int ffp_sr_enhance(ffp_sr* s, const uint8_t* bgr, int h, int w, int tile, int ti
   return ffp_sr_enhance_batch(s, 1, ins, hs, ws, tile, tile_pad, pre_pad, outs);
 }
 
-int ffp_sr_enhance_crops_dev(ffp_sr* s, const uint8_t* d_frame, int H, int W, const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap,
-                             int64_t* out_offsets) {
+static int sr_crops_impl(ffp_sr* s, const uint8_t* d_frame, int H, int W, const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap,
+                         int64_t* out_offsets, bool wait) {
   FFP_API_BEGIN
   FFP_CHECK(s && d_frame && boxes && n > 0 && d_out && out_offsets, FFP_ERR_ARG, "bad argument");
   SrEngine& e = s->eng;
   FFP_HIP(hipSetDevice(e.device()));
+  e.wait_done();                      // one enhancement in flight per handle: its scratch and plan tables are about to be reused
   const int sc = e.scale();
   std::vector<SrImage> v(n);
   std::vector<int4> hb(n);
@@ -365,7 +366,24 @@ int ffp_sr_enhance_crops_dev(ffp_sr* s, const uint8_t* d_frame, int H, int W, co
   FFP_HIP(hipMemcpyAsync(e.scratch_offs.p, offs.data(), sizeof(long long) * n, hipMemcpyHostToDevice, e.stream()));
   launch_crop_gather(d_frame, W, e.scratch_boxes.as<int4>(), e.scratch_offs.as<long long>(), n, e.scratch_in.as<uint8_t>(), e.stream());
   FFP_HIP(hipStreamSynchronize(e.stream()));
-  e.enhance_dev(e.scratch_in.as<uint8_t>(), d_out, v, 0, 10, 0);
+  e.enhance_dev(e.scratch_in.as<uint8_t>(), d_out, v, 0, 10, 0, wait);
+  FFP_API_END
+}
+
+int ffp_sr_enhance_crops_dev(ffp_sr* s, const uint8_t* d_frame, int H, int W, const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap,
+                             int64_t* out_offsets) {
+  return sr_crops_impl(s, d_frame, H, W, boxes, n, d_out, out_cap, out_offsets, true);
+}
+
+int ffp_sr_enhance_crops_dev_async(ffp_sr* s, const uint8_t* d_frame, int H, int W, const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap,
+                                   int64_t* out_offsets) {
+  return sr_crops_impl(s, d_frame, H, W, boxes, n, d_out, out_cap, out_offsets, false);
+}
+
+int ffp_sr_wait(ffp_sr* s) {
+  FFP_API_BEGIN
+  FFP_CHECK(s, FFP_ERR_ARG, "null handle");
+  s->eng.wait_done();
   FFP_API_END
 }
 

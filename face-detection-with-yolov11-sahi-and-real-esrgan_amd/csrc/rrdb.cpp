@@ -109,8 +109,19 @@ void SrEngine::build_plan(SrPlan& P, const std::vector<int>& hs, const std::vect
   P.d_core_off.alloc(sizeof(long long) * (n + 1));
 }
 
-void SrEngine::enhance_dev(const uint8_t* d_in, uint8_t* d_out, const std::vector<SrImage>& imgs, int tile, int tile_pad, int pre_pad) {
+void SrEngine::wait_done() {
   FFP_HIP(hipSetDevice(device_));
+  FFP_HIP(hipStreamSynchronize(st_));
+  if (pending_) {
+    if (prof.enabled) prof.collect();
+    FFP_HIP(hipEventElapsedTime(&last_ms, ev_[0], ev_[1]));
+    pending_ = false;
+  }
+}
+
+void SrEngine::enhance_dev(const uint8_t* d_in, uint8_t* d_out, const std::vector<SrImage>& imgs, int tile, int tile_pad, int pre_pad, bool wait) {
+  FFP_HIP(hipSetDevice(device_));
+  if (pending_) wait_done();
   FFP_CHECK(!imgs.empty(), FFP_ERR_ARG, "enhance: empty batch");
   FFP_CHECK(tile_pad >= 0 && pre_pad >= 0, FFP_ERR_ARG, "enhance: negative padding");
   const int s = scale_;
@@ -175,11 +186,10 @@ void SrEngine::enhance_dev(const uint8_t* d_in, uint8_t* d_out, const std::vecto
   P.execute(st_, &prof);
   launch_sr_post(P.out, P.d_dsts.as<SrDst>(), P.d_core_off.as<long long>(), tot, d_out, st_);
   FFP_HIP(hipEventRecord(ev_[1], st_));
-  FFP_HIP(hipStreamSynchronize(st_));
-  if (prof.enabled) prof.collect();
-  FFP_HIP(hipEventElapsedTime(&last_ms, ev_[0], ev_[1]));
   last_conv_flops = P.conv_flops;
   last_conv_launches = P.conv_launches;
+  pending_ = true;
+  if (wait) wait_done();
 }
 
 }  // namespace ffp

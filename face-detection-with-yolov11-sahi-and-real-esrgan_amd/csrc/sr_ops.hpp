@@ -46,7 +46,10 @@ class SrEngine {
   int device() const { return device_; }
   hipStream_t stream() const { return st_; }
   // all images live in device memory: inputs at d_in + in_off (BGR u8, in_stride bytes/row), outputs at d_out + out_off
-  void enhance_dev(const uint8_t* d_in, uint8_t* d_out, const std::vector<SrImage>& imgs, int tile, int tile_pad, int pre_pad);
+  // wait = false: return as soon as the work is enqueued on the engine's stream (wait_done() completes it), so that the
+  // caller can overlap the next frame's detection (own stream) with this frame's super-resolution
+  void enhance_dev(const uint8_t* d_in, uint8_t* d_out, const std::vector<SrImage>& imgs, int tile, int tile_pad, int pre_pad, bool wait = true);
+  void wait_done();
 
   DevBuf scratch_in, scratch_out, scratch_boxes, scratch_offs;
   ConvProfile prof;
@@ -64,6 +67,7 @@ class SrEngine {
   DType dt_ = F16;
   hipStream_t st_ = nullptr;
   hipEvent_t ev_[2];
+  bool pending_ = false;
 };
 
 }  // namespace ffp

@@ -93,8 +93,12 @@ def exchange_detections(local_dets, local_counts, world: int):
         return local_dets, local_counts
     import torch
     import torch.distributed as dist
-    g = torch.empty((world * local_dets.shape[0],) + tuple(local_dets.shape[1:]), dtype=local_dets.dtype, device=local_dets.device)
-    gc = torch.empty((world * local_counts.shape[0],), dtype=local_counts.dtype, device=local_counts.device)
+    dev = local_dets.device
+    if dist.get_backend() == "gloo" and dev.type == "cuda":      # rehearsal on a box without RCCL peers: stage through the host
+        g, gc = exchange_detections(local_dets.cpu(), local_counts.cpu(), world)
+        return g.to(dev), gc.to(dev)
+    g = torch.empty((world * local_dets.shape[0],) + tuple(local_dets.shape[1:]), dtype=local_dets.dtype, device=dev)
+    gc = torch.empty((world * local_counts.shape[0],), dtype=local_counts.dtype, device=dev)
     dist.all_gather_into_tensor(g, local_dets.contiguous())
     dist.all_gather_into_tensor(gc, local_counts.contiguous())
     return g, gc
@@ -158,14 +162,19 @@ class FramePipeline:
                                              cfg.merge_cap, outn.data_ptr()))
         return out, outn
 
-    def enhance_crops(self, d_frame_bgr, H: int, W: int, boxes: np.ndarray):
-        """Real-ESRGAN x4 on crops of a resident BGR frame. Returns (uint8 cuda tensor with all outputs, offsets)."""
+    def enhance_crops(self, d_frame_bgr, H: int, W: int, boxes: np.ndarray, wait: bool = True, slot: int = 0):
+        """Real-ESRGAN x4 on crops of a resident BGR frame. Returns (uint8 cuda tensor with all outputs, offsets).
+        wait=False enqueues on the enhancer's stream and returns; call wait_sr() before reading the tensor."""
         torch = self.torch
         n = boxes.shape[0]
         tot = int(sum(((int(b[3] - b[1]) * 4) * (int(b[2] - b[0]) * 4) * 3 + 15) // 16 * 16 for b in boxes))
-        out = self._buf("sr_out", (tot,), torch.uint8)
+        out = self._buf(f"sr_out{slot}", (tot,), torch.uint8)
         offs = np.zeros(n + 1, np.int64)
         b = np.ascontiguousarray(boxes, np.int32)
-        _lib._check(_lib.lib().ffp_sr_enhance_crops_dev(self.sr.handle, d_frame_bgr.data_ptr(), H, W, _lib._ip(b), n, out.data_ptr(), tot,
+        fn = _lib.lib().ffp_sr_enhance_crops_dev if wait else _lib.lib().ffp_sr_enhance_crops_dev_async
+        _lib._check(fn(self.sr.handle, d_frame_bgr.data_ptr(), H, W, _lib._ip(b), n, out.data_ptr(), tot,
                                                         offs.ctypes.data_as(C.POINTER(C.c_int64))))
         return out, offs
+
+    def wait_sr(self):
+        _lib._check(_lib.lib().ffp_sr_wait(self.sr.handle))

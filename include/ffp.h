@@ -175,6 +175,13 @@ int ffp_sr_enhance_batch(ffp_sr* s, int n, const uint8_t* const* imgs, const int
 int ffp_sr_enhance_crops_dev(ffp_sr* s, const uint8_t* d_frame_bgr, int H, int W, const int32_t* boxes_xyxy, int n,
                              uint8_t* d_out, size_t out_cap, int64_t* out_offsets);
 
+/* Same, but returns once the work is enqueued on the enhancer's own HIP stream; ffp_sr_wait() blocks until d_out is
+ * complete. Lets a caller overlap frame i's super-resolution with frame i+1's detection (the detector handle has its
+ * own stream). d_frame and d_out must stay untouched until ffp_sr_wait (or the next call on the handle) returns. */
+int ffp_sr_enhance_crops_dev_async(ffp_sr* s, const uint8_t* d_frame_bgr, int H, int W, const int32_t* boxes_xyxy, int n,
+                                   uint8_t* d_out, size_t out_cap, int64_t* out_offsets);
+int ffp_sr_wait(ffp_sr* s);
+
 /* ---------------------------------------------------------------------------------------------------------
  * single-operator entry points (layer-wise parity tests; host NHWC fp32 in/out, computed on `device` in `precision`)
  * ------------------------------------------------------------------------------------------------------- */
