@@ -83,6 +83,8 @@ _SIGS = {
     "ffp_sr_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "ffp_sr_profile_count": (C.c_int, [C.c_void_p, _p(C.c_int32)]),
     "ffp_sr_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, _p(C.c_double), _p(C.c_float), _p(C.c_int32)]),
+    "ffp_op_conv2d_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, _p(C.c_float)]),
     "ffp_op_conv2d": (C.c_int, [C.c_int, C.c_int, _p(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_float), _p(C.c_float), C.c_int,
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_float), C.c_float, _p(C.c_float)]),
 }
@@ -369,3 +371,10 @@ def op_conv2d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], stride: int
     _check(lib().ffp_op_conv2d(device, precision, _fp(x), n, h, wd, cin, _fp(w), _fp(bb) if bb is not None else None, cout, k, stride,
                                groups, act, int(up), _fp(rr) if rr is not None else None, res_scale, _fp(y)))
     return y
+
+
+def op_conv2d_time(n, h, w, cin, cout, k=3, stride=1, up=False, precision=PREC_F16, iters=50, dbg=0, shape=-1, device=0) -> float:
+    """Tuning hook: mean microseconds per launch of one dense conv on synthetic data (see ffp_op_conv2d_time)."""
+    us = C.c_float(0)
+    _check(lib().ffp_op_conv2d_time(device, precision, n, h, w, cin, cout, k, stride, int(up), iters, dbg, shape, C.byref(us)))
+    return us.value

@@ -472,4 +472,64 @@ int ffp_op_conv2d(int device, int precision, const float* x, int n, int h, int w
   FFP_API_END
 }
 
+// tuning hook: average device time (HIP events) of `iters` launches of one dense convolution on synthetic data
+int ffp_op_conv2d_time(int device, int precision, int n, int h, int w, int cin, int cout, int k, int stride, int up, int iters,
+                       int dbg_mask, int force_shape, float* out_us) {
+  FFP_API_BEGIN
+  FFP_CHECK(out_us && n > 0 && iters > 0, FFP_ERR_ARG, "bad arguments");
+  int ndev = 0;
+  FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "no HIP device %d", device);
+  FFP_HIP(hipSetDevice(device));
+  conv_kernels_init();
+  const DType T = precision == FFP_PREC_F16 ? F16 : F32;
+  hipStream_t st;
+  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  try {
+    std::vector<float> wt((size_t)cout * cin * k * k), bias(cout, 0.1f);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
+    for (auto& v : wt) v = rnd() * 0.1f;
+    PackedConv pc;
+    pack_conv(pc, "bench", wt.data(), bias.data(), cout, cin, k, 1, T, st, precision == FFP_PREC_F32X3);
+    const int hi = up ? h * 2 : h, wi = up ? w * 2 : w;
+    const int ho = (hi + 2 * (k / 2) - k) / stride + 1, wo = (wi + 2 * (k / 2) - k) / stride + 1;
+    Level lin, lout;
+    lin.build(std::vector<int>(n, h), std::vector<int>(n, w), st);
+    lout.build(std::vector<int>(n, ho), std::vector<int>(n, wo), st);
+    const size_t nin = (size_t)lin.total_px * pc.cin, nout = (size_t)lout.total_px * cout;
+    DevBuf din(nin * dsize(T) + 256), dout(nout * dsize(T) + 256);
+    {
+      std::vector<float> hx(std::min(nin, (size_t)1 << 22));
+      for (auto& v : hx) v = rnd();
+      if (T == F32) {
+        for (size_t o = 0; o < nin; o += hx.size()) FFP_HIP(hipMemcpy((float*)din.p + o, hx.data(), std::min(hx.size(), nin - o) * 4, hipMemcpyHostToDevice));
+      } else {
+        std::vector<_Float16> hh(hx.size());
+        for (size_t i = 0; i < hx.size(); ++i) hh[i] = (_Float16)hx[i];
+        for (size_t o = 0; o < nin; o += hh.size()) FFP_HIP(hipMemcpy((_Float16*)din.p + o, hh.data(), std::min(hh.size(), nin - o) * 2, hipMemcpyHostToDevice));
+      }
+    }
+    ConvOp o;
+    o.pc = &pc; o.stride = stride; o.act = ACT_SILU; o.up = up; o.dbg = dbg_mask; o.force_shape = force_shape;
+    o.in = TView{din.p, T, pc.cin, 0, pc.cin, &lin};
+    o.out = TView{dout.p, T, cout, 0, cout, &lout};
+    for (int i = 0; i < 3; ++i) launch_conv(o, st);
+    hipEvent_t e0, e1;
+    FFP_HIP(hipEventCreate(&e0)); FFP_HIP(hipEventCreate(&e1));
+    FFP_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) launch_conv(o, st);
+    FFP_HIP(hipEventRecord(e1, st));
+    FFP_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    FFP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *out_us = ms * 1e3f / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  } catch (...) {
+    (void)hipStreamDestroy(st);
+    throw;
+  }
+  (void)hipStreamDestroy(st);
+  FFP_API_END
+}
+
 }  // extern "C"

@@ -35,7 +35,9 @@ struct ConvArgs {
   int out_cs, out_coff, cout;
   int r1_cs, r1_coff, r2_cs, r2_coff;
   float s1, s2;
-  int act, out_f32, up, n_nblk, ncg, ntiles32, vec_ok;
+  int act, out_f32, up, n_nblk, ncg, ntiles32, vec_ok, fast_out;
+  int force_shape;   // tuning only: -1 auto
+  int dbg;   // tuning only (ffp_op_conv2d_time): 1 skip stores, 2 skip MFMAs, 4 skip chunk refetch, 8 skip LDS stash
 };
 
 // fp32 storage with operands split into fp16 hi + lo parts: a*b ~= ah*bh + ah*bl + al*bh (three fp16 MFMAs, fp32
@@ -86,7 +88,9 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == ACT_SILU) return v / (1.0f + expf(-v));
+  // SiLU with the hardware exp2 / rcp (1 ulp each): ~6 VALU ops instead of ~25 for expf + IEEE divide; the epilogue of a
+  // 256 px x 64 ch block otherwise spends ~2.7 us in the activation alone
+  if (act == ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
   if (act == ACT_LRELU) return v >= 0.f ? v : v * 0.2f;
   return v;
 }
@@ -272,19 +276,27 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
+  // bias for this lane's 16 channels of each 32-channel tile: fetched now, consumed in the epilogue (no exposed L2 round trip there)
+  float4 bias_r[NIW][4];
+#pragma unroll
+  for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      bias_r[ni][g] = *reinterpret_cast<const float4*>(a.bias + min(ntile0 + ni, a.ntiles32 - 1) * 32 + 8 * g + 4 * hh);
+
   fetch(0);
   stash(smem);
   __syncthreads();
   int cur = 0;
   for (int c0 = 0; c0 < a.cin; c0 += KC) {
     const bool more = c0 + KC < a.cin;
-    if (more) fetch(c0 + KC);                              // in flight while this chunk is multiplied
+    if (more && !(a.dbg & 4)) fetch(c0 + KC);              // in flight while this chunk is multiplied
     const unsigned char* sb = smem + cur * G::BUF;
     const unsigned char* sw = sb + G::IN_BYTES + ((wn * NIW) * TAPS * KCG) * WFRAG + lane * 16;
     const int kmax = min(KC, a.cin_pad - c0) / KG;
 #pragma unroll
     for (int ks = 0; ks < KCG; ++ks) {
-      if (ks < kmax) {
+      if (ks < kmax && !(a.dbg & 2)) {
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
           const int ky = tap / KS, kx = tap % KS;
@@ -318,12 +330,96 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
         }
       }
     }
-    if (more) stash(smem + (cur ^ 1) * G::BUF);            // the other stage was last read one barrier ago
+    if (more && !(a.dbg & 8)) stash(smem + (cur ^ 1) * G::BUF);   // the other stage was last read one barrier ago
     __syncthreads();
     cur ^= 1;
   }
 
-  // ---- epilogue: bias, activation, residual(s), store. Lane = one pixel; regs 4g..4g+3 = channels 8g+4hh..+3.
+  // ---- epilogue A (aligned outputs): transpose each 32 px x 32 ch accumulator tile through a wave-private LDS tile so
+  // that global stores (and residual loads) are whole pixel rows — 8 (fp32) / 4 (fp16) consecutive lanes cover one
+  // pixel's 32 channels with 16-byte accesses. The direct form (epilogue B) writes 16 scattered bytes per lane and
+  // measured 40-65 % of the kernel time on store-heavy layers.
+  if (a.fast_out && !(a.dbg & 1)) {
+    constexpr int EROW = 32 * 4 + 16;                 // fp32 staging row per pixel (+16 B pad)
+    constexpr int CPL = 16 / ES;                      // output channels per 16-byte chunk (4 fp32 / 8 fp16)
+    constexpr int LPP = 32 / CPL;                     // lanes per pixel row (8 / 4)
+    constexpr int PPI = 64 / LPP;                     // pixels per store instruction (8 / 16)
+    unsigned char* et = smem + wave * (32 * EROW);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int f = wm * MI + mi;
+#pragma unroll
+      for (int ni = 0; ni < NIW; ++ni) {
+        const int nt = ntile0 + ni;
+        if (nt >= a.ntiles32) continue;
+        // this lane's share of the tile in the transposed (row) order: pixel index + validity + residual chunks, issued
+        // BEFORE the LDS round trip so that their latency overlaps it
+        long long gps[32 / PPI];
+        bool oks[32 / PPI];
+        uint4 r1v[32 / PPI], r2v[32 / PPI];
+#pragma unroll
+        for (int it = 0; it < 32 / PPI; ++it) {
+          const int pp = it * PPI + lane / LPP, ch0 = (lane % LPP) * CPL;
+          if (KS == 1) {
+            gps[it] = out_base + f * 32 + pp;
+            oks[it] = gps[it] < a.total_px;
+          } else {
+            const int oy = oy0 + 2 * f + (pp >> 4), ox = ox0 + (pp & 15);
+            oks[it] = oy < Ho && ox < Wo;
+            gps[it] = out_base + (long long)oy * Wo + ox;
+          }
+          oks[it] = oks[it] && nt * 32 + ch0 < a.cout;
+          r1v[it] = make_uint4(0u, 0u, 0u, 0u); r2v[it] = r1v[it];
+          if (oks[it] && a.res1)
+            r1v[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const GT*>(a.res1) + (size_t)gps[it] * a.r1_cs + a.r1_coff + nt * 32 + ch0);
+          if (oks[it] && a.res2)
+            r2v[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const GT*>(a.res2) + (size_t)gps[it] * a.r2_cs + a.r2_coff + nt * 32 + ch0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // previous tile's staging reads have landed in registers
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ch = 8 * g + 4 * hh;
+          const float4 bv = bias_r[ni][g];
+          float4 v;
+          v.x = apply_act(acc[ni][mi][4 * g + 0] + bv.x, a.act);
+          v.y = apply_act(acc[ni][mi][4 * g + 1] + bv.y, a.act);
+          v.z = apply_act(acc[ni][mi][4 * g + 2] + bv.z, a.act);
+          v.w = apply_act(acc[ni][mi][4 * g + 3] + bv.w, a.act);
+          *reinterpret_cast<float4*>(et + p * EROW + ch * 4) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS is in order per wave; make the tile visible to all lanes
+#pragma unroll
+        for (int it = 0; it < 32 / PPI; ++it) {
+          const int pp = it * PPI + lane / LPP, ch0 = (lane % LPP) * CPL;
+          if (!oks[it]) continue;
+          float v[CPL];
+#pragma unroll
+          for (int q = 0; q < CPL / 4; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4*>(et + pp * EROW + (ch0 + 4 * q) * 4);
+            v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+          }
+          if (a.res1) {
+            const GT* r = reinterpret_cast<const GT*>(&r1v[it]);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) v[q] = v[q] * a.s1 + (float)r[q];
+          }
+          if (a.res2) {
+            const GT* r = reinterpret_cast<const GT*>(&r2v[it]);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) v[q] = v[q] * a.s2 + (float)r[q];
+          }
+          uint4 ov;
+          GT* o = reinterpret_cast<GT*>(&ov);
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) o[q] = (GT)v[q];
+          *reinterpret_cast<uint4*>(reinterpret_cast<GT*>(a.out) + (size_t)gps[it] * a.out_cs + a.out_coff + nt * 32 + ch0) = ov;
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- epilogue B (any alignment / channel count): lane = one pixel; regs 4g..4g+3 = channels 8g+4hh..+3.
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int f = wm * MI + mi;
@@ -337,7 +433,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
       ok = oy < Ho && ox < Wo;
       gp = out_base + (long long)oy * Wo + ox;
     }
-    if (!ok) continue;
+    if (!ok || (a.dbg & 1)) continue;
 #pragma unroll
     for (int ni = 0; ni < NIW; ++ni) {
       const int nt = ntile0 + ni;
@@ -347,7 +443,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
         const int ch = nt * 32 + 8 * g + 4 * hh;
         if (ch >= a.cout) continue;
         float v[4];
-        const float4 bv = *reinterpret_cast<const float4*>(a.bias + ch);
+        const float4 bv = bias_r[ni][g];
         v[0] = acc[ni][mi][4 * g + 0] + bv.x;
         v[1] = acc[ni][mi][4 * g + 1] + bv.y;
         v[2] = acc[ni][mi][4 * g + 2] + bv.z;
@@ -418,44 +514,44 @@ template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int K
   }
 };
 
-// chunk sizes (input channels per LDS stage), chosen so that 2 x (input tile + weight fragments) fits the 160 KiB LDS
-//                                   shape: 0 wide, 1 narrow2, 2 narrow1
+// Chunk sizes (input channels per LDS stage) per shape {0 wide, 1 wideH, 2 narrow2, 3 narrow2H, 4 narrow1, 5 narrow1H}: the largest
+// that keeps 2 x (input tile + weight fragments) <= 80 KiB, i.e. TWO workgroups resident per CU, so that one
+// workgroup's prologue / epilogue overlaps the other's MFMA phase (measured: an occupancy-2 32-channel block beats an
+// occupancy-1 64-channel block by 1.3x on conv_hr). Where even the minimum chunk does not fit 80 KiB the minimum is used.
 template <typename T, int KS, int STRIDE, int SHAPE> struct KCof;
-template <> struct KCof<float, 1, 1, 0> { static constexpr int v = 16; };
-template <> struct KCof<float, 1, 1, 1> { static constexpr int v = 16; };
-template <> struct KCof<float, 1, 1, 2> { static constexpr int v = 16; };
-template <> struct KCof<float, 3, 1, 0> { static constexpr int v = 8; };
-template <> struct KCof<float, 3, 1, 1> { static constexpr int v = 8; };
-template <> struct KCof<float, 3, 1, 2> { static constexpr int v = 8; };
-template <> struct KCof<float, 3, 2, 0> { static constexpr int v = 8; };
-template <> struct KCof<float, 3, 2, 1> { static constexpr int v = 16; };
-template <> struct KCof<float, 3, 2, 2> { static constexpr int v = 16; };
-template <> struct KCof<_Float16, 1, 1, 0> { static constexpr int v = 64; };
-template <> struct KCof<_Float16, 1, 1, 1> { static constexpr int v = 64; };
-template <> struct KCof<_Float16, 1, 1, 2> { static constexpr int v = 128; };
-template <> struct KCof<_Float16, 3, 1, 0> { static constexpr int v = 16; };
-template <> struct KCof<_Float16, 3, 1, 1> { static constexpr int v = 32; };
-template <> struct KCof<_Float16, 3, 1, 2> { static constexpr int v = 32; };
-template <> struct KCof<_Float16, 3, 2, 0> { static constexpr int v = 16; };
-template <> struct KCof<_Float16, 3, 2, 1> { static constexpr int v = 32; };
-template <> struct KCof<_Float16, 3, 2, 2> { static constexpr int v = 32; };
+#define FFP_KC(T, KS, S, a, b, c, d, e, f)                                           \
+  template <> struct KCof<T, KS, S, 0> { static constexpr int v = a; };              \
+  template <> struct KCof<T, KS, S, 1> { static constexpr int v = b; };              \
+  template <> struct KCof<T, KS, S, 2> { static constexpr int v = c; };              \
+  template <> struct KCof<T, KS, S, 3> { static constexpr int v = d; };              \
+  template <> struct KCof<T, KS, S, 4> { static constexpr int v = e; };              \
+  template <> struct KCof<T, KS, S, 5> { static constexpr int v = f; };
+//                  wide wideH  n2  n2H  n1  n1H
+FFP_KC(float, 1, 1,   16,  32,  16,  32, 16,  32)
+FFP_KC(float, 3, 1,    8,   8,   8,   8,  8,  16)
+FFP_KC(float, 3, 2,    8,   8,   8,   8,  8,   8)
+FFP_KC(_Float16, 1, 1, 32,  64,  32,  64, 32,  64)
+FFP_KC(_Float16, 3, 1, 16,  16,  16,  16, 16,  32)
+FFP_KC(_Float16, 3, 2, 16,  16,  16,  16, 16,  16)
+FFP_KC(X3, 1, 1,      16,  32,  16,  32, 16,  32)
+FFP_KC(X3, 3, 1,      16,  16,  16,  16, 16,  16)
+FFP_KC(X3, 3, 2,      16,  16,  16,  16, 16,  16)
+#undef FFP_KC
 
 // Shape selection: six workgroup shapes per (dtype, k, stride) — {wide 128ch, narrow2 64ch, narrow1 32ch} x {full, half
 // pixel tile}. The largest block (most operand reuse) that still yields >= 2 workgroups per CU wins; layers with few
 // pixels (stride-32 maps, face crops) fall through to smaller blocks so that the whole chip is busy.
-template <int KS, int STRIDE, int SHAPE> struct KCof<X3, KS, STRIDE, SHAPE> { static constexpr int v = 16; };
-
 template <typename T, int KS, int STRIDE> struct Family {
   static constexpr int MIW = STRIDE == 2 ? 2 : 4;   // wide: 2x2 waves
   static constexpr int MIN = STRIDE == 2 ? 1 : 2;   // narrow: 4x1 waves
   static constexpr int MIWH = MIW / 2;
   static constexpr int MINH = MIN > 1 ? MIN / 2 : 1;
   using Wide = Cfg<T, KS, STRIDE, 2, 2, MIW, 2, KCof<T, KS, STRIDE, 0>::v>;
-  using Narrow2 = Cfg<T, KS, STRIDE, 4, 1, MIN, 2, KCof<T, KS, STRIDE, 1>::v>;
-  using Narrow1 = Cfg<T, KS, STRIDE, 4, 1, MIN, 1, KCof<T, KS, STRIDE, 2>::v>;
-  using WideH = Cfg<T, KS, STRIDE, 2, 2, MIWH, 2, KCof<T, KS, STRIDE, 0>::v>;
-  using Narrow2H = Cfg<T, KS, STRIDE, 4, 1, MINH, 2, KCof<T, KS, STRIDE, 1>::v>;
-  using Narrow1H = Cfg<T, KS, STRIDE, 4, 1, MINH, 1, KCof<T, KS, STRIDE, 2>::v>;
+  using WideH = Cfg<T, KS, STRIDE, 2, 2, MIWH, 2, KCof<T, KS, STRIDE, 1>::v>;
+  using Narrow2 = Cfg<T, KS, STRIDE, 4, 1, MIN, 2, KCof<T, KS, STRIDE, 2>::v>;
+  using Narrow2H = Cfg<T, KS, STRIDE, 4, 1, MINH, 2, KCof<T, KS, STRIDE, 3>::v>;
+  using Narrow1 = Cfg<T, KS, STRIDE, 4, 1, MIN, 1, KCof<T, KS, STRIDE, 4>::v>;
+  using Narrow1H = Cfg<T, KS, STRIDE, 4, 1, MINH, 1, KCof<T, KS, STRIDE, 5>::v>;
   static constexpr bool HAS_NH = MIN > 1;
   static void init() {
     Wide::init(); Narrow2::init(); Narrow1::init(); WideH::init();
@@ -466,25 +562,27 @@ template <typename T, int KS, int STRIDE> struct Family {
     return tiles * ((a.ntiles32 * 32 + C::BLOCK_N - 1) / C::BLOCK_N);
   }
   static int choose(const ConvArgs& a, Level* out_lvl) {
-    constexpr long long ENOUGH = 2 * 256;
+    // candidates in decreasing block size; first pass: shapes that allow two resident workgroups per CU (LDS <= 80 KiB) and fill the chip; second pass: any shape with enough work; else the shape with the most workgroups.
+    constexpr long long ENOUGH = 192;     // >= 3/4 of the 256 CUs get a workgroup: measured better than insisting on two for the SR body convs
+    struct Cand { int id; long long n; bool valid; bool occ2; };
+    const bool wide_ok = a.ntiles32 >= 3 && (KS == 1 || STRIDE == 2);
+    const Cand c[6] = {
+        {0, wgs<Wide>(a, out_lvl), Wide::OK && wide_ok, Wide::LDS <= 80 * 1024},
+        {1, wgs<WideH>(a, out_lvl), WideH::OK && wide_ok, WideH::LDS <= 80 * 1024},
+        {2, wgs<Narrow2>(a, out_lvl), Narrow2::OK && a.ntiles32 >= 2, Narrow2::LDS <= 80 * 1024},
+        {3, wgs<Narrow2H>(a, out_lvl), HAS_NH && Narrow2H::OK && a.ntiles32 >= 2, Narrow2H::LDS <= 80 * 1024},
+        {4, wgs<Narrow1>(a, out_lvl), Narrow1::OK, Narrow1::LDS <= 80 * 1024},
+        {5, wgs<Narrow1H>(a, out_lvl), HAS_NH && Narrow1H::OK, Narrow1H::LDS <= 80 * 1024}};
+    for (const Cand& k : c) if (k.valid && k.occ2 && k.n >= ENOUGH) return k.id;
+    for (const Cand& k : c) if (k.valid && k.n >= ENOUGH) return k.id;
     int best = -1;
     long long best_n = -1;
-    auto consider = [&](int id, long long n, bool valid) {
-      if (!valid || best_n >= ENOUGH) return;
-      if (n >= ENOUGH || n > best_n) { best = id; best_n = n; }
-    };
-    // 3x3: a 128-channel block needs 36 KiB of weights per stage -> one workgroup per CU; 64-channel blocks keep two resident
-    consider(0, wgs<Wide>(a, out_lvl), Wide::OK && a.ntiles32 >= 3 && (KS == 1 || STRIDE == 2));
-    consider(1, wgs<WideH>(a, out_lvl), WideH::OK && a.ntiles32 >= 3 && (KS == 1 || STRIDE == 2));
-    consider(2, wgs<Narrow2>(a, out_lvl), Narrow2::OK && a.ntiles32 >= 2);
-    if (HAS_NH) consider(3, wgs<Narrow2H>(a, out_lvl), Narrow2H::OK && a.ntiles32 >= 2);
-    consider(4, wgs<Narrow1>(a, out_lvl), Narrow1::OK);
-    if (HAS_NH) consider(5, wgs<Narrow1H>(a, out_lvl), Narrow1H::OK);
+    for (const Cand& k : c) if (k.valid && k.n > best_n) { best = k.id; best_n = k.n; }
     if (best < 0) fail(FFP_ERR_STATE, "conv: no workgroup shape fits");
     return best;
   }
   static void launch(ConvArgs& a, Level* out_lvl, hipStream_t st) {
-    switch (choose(a, out_lvl)) {
+    switch (a.force_shape >= 0 ? a.force_shape : choose(a, out_lvl)) {
       case 0: Wide::launch(a, out_lvl, st); break;
       case 1: WideH::launch(a, out_lvl, st); break;
       case 2: Narrow2::launch(a, out_lvl, st); break;
@@ -556,6 +654,15 @@ static ConvArgs make_args(const ConvOp& op) {
     vec = vec && op.res2.cs % 4 == 0 && op.res2.coff % 4 == 0;
   }
   a.vec_ok = vec ? 1 : 0;
+  {   // epilogue A needs 16-byte chunks of the OUTPUT element type everywhere (out + residuals) and out dtype == activation dtype
+    const int cpl = 16 / dsize(pc.dt);
+    bool f = op.out.dt == pc.dt && pc.cout % cpl == 0 && op.out.cs % cpl == 0 && op.out.coff % cpl == 0;
+    if (op.has_res1) f = f && op.res1.cs % cpl == 0 && op.res1.coff % cpl == 0;
+    if (op.has_res2) f = f && op.res2.cs % cpl == 0 && op.res2.coff % cpl == 0;
+    a.fast_out = f ? 1 : 0;
+  }
+  a.dbg = op.dbg;
+  a.force_shape = op.force_shape;
   if (pc.k == 1) FFP_CHECK(op.in.lvl->total_px == op.out.lvl->total_px, FFP_ERR_ARG, "conv %s: 1x1 levels differ", pc.name.c_str());
   return a;
 }

@@ -18,6 +18,8 @@ struct ConvOp {
   TView res1, res2;
   float s1 = 1.f, s2 = 1.f;
   double flops = 0;   // 2*MAC, algorithmic (unpadded)
+  int dbg = 0;        // tuning only: phase-skip mask (see ConvArgs::dbg)
+  int force_shape = -1;   // tuning only: 0 wide .. 5 narrow1H
 };
 void launch_conv(const ConvOp& op, hipStream_t st);
 // image-input 3x3 convs (3 real channels: YOLO stem, ESRGAN conv_first) as a direct VALU kernel (ops_misc.hip)

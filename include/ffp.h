@@ -193,6 +193,12 @@ int ffp_op_conv2d(int device, int precision, const float* x, int n, int h, int w
                   const float* bias, int cout, int k, int stride, int groups, int act, int up, const float* res,
                   float res_scale, float* y);
 
+/* Tuning hook: mean device time (HIP events, microseconds) of `iters` back-to-back launches of one dense convolution on
+ * synthetic data. dbg_mask skips kernel phases (1 stores, 2 MFMAs, 4 chunk refetch, 8 LDS stash) to attribute time —
+ * results are then wrong by construction; force_shape pins the workgroup shape (-1: automatic). */
+int ffp_op_conv2d_time(int device, int precision, int n, int h, int w, int cin, int cout, int k, int stride, int up, int iters,
+                       int dbg_mask, int force_shape, float* out_us);
+
 /* timing hooks for bench.py: HIP-event milliseconds of the last call on the handle, by stage
  * stage: 0 total, 1 preprocess, 2 network, 3 decode+nms, 4 merge */
 int ffp_det_last_ms(ffp_det* d, int stage, float* out_ms);
