@@ -203,12 +203,20 @@ def main():
             prof += [dict(p, stage="sr") for p in pipe.sr.profile()]
         prof.sort(key=lambda p: -p["ms"])
         roof = None
+        pmc = {}
+        try:    # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), keyed by kernel variant
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh).get("kernels", {})
+        except Exception:
+            pmc = {}
         if prof:
             d = prof[0]
             dtp = d["variant"].split("_")[0]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
             roof = {"bound": "mfma", "kernel": f"conv_mfma_kernel<{d['variant']}> ({d['stage']})", "achieved": round(ach, 2),
-                    "peak": PEAK_TFLOPS[dtp], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtp], 4), "traffic": None,
+                    "peak": PEAK_TFLOPS[dtp], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtp], 4),
+                    "traffic": (round(pmc[d["variant"]]["hbm_bytes_per_launch"]) if d["variant"] in pmc else None),
+                    "traffic_source": ("profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if d["variant"] in pmc else None),
                     "launches": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2),
                     "flops_per_launch": d["flops"] / max(d["launches"], 1)}
         stage_ms = pipe.det.last_ms()
