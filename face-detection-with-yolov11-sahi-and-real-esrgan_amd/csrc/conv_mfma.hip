@@ -138,7 +138,11 @@ template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int K
   static constexpr int BUF = IN_BYTES + W_FRAGS * WFRAG;    // one LDS stage: input tile chunk + its weights
   static constexpr int LDS = 2 * BUF;                       // double buffered
   static constexpr int NVI = NPIX * VPP, NVW = W_FRAGS * VPF;
-  static constexpr int RI = (NVI + 255) / 256, RW = (NVW + 255) / 256;   // prefetch registers (16 B each) per thread
+  static constexpr int RI = (NVI + 255) / 256, RW = (NVW + 255) / 256;   // prefetch registers (16 B each) per thread and chunk
+  // chunks kept in flight global->registers ahead of the one being multiplied: as many (<= 4) as fit a 2-waves-per-SIMD
+  // register budget next to the accumulators. Short chunks (0.25 us of MFMA at KC = 16) need several L2 round trips in flight.
+  static constexpr int DEPTH_RAW = (256 - NIW * MI * 16 - 80 - 3 * (RI + RW)) / (4 * (RI + RW));   // accumulators, ~80 misc, address slots
+  static constexpr int DEPTH = DEPTH_RAW < 1 ? 1 : DEPTH_RAW > 4 ? 4 : DEPTH_RAW;
   static_assert(KC % KG == 0 && WM * WN == 4, "geometry");
 };
 
@@ -187,69 +191,82 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
   const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in);
   const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.wpk);
 
-  // per-thread staging slots: which global vector each of this thread's RI + RW registers carries (chunk independent part)
-  long long isrc[RI];          // byte offset of the pixel record (-1: outside the image -> zeros)
+  // Global operands are read with raw BUFFER loads: the resource base is wave-uniform (this workgroup's image / pixel run,
+  // the packed weights), the per-lane part a 32-bit byte offset, and an out-of-image / past-the-end slot uses offset
+  // 0xFFFFFFFF, which the hardware range check turns into zeros — conv zero padding without a branch or a select, so the
+  // loads stay straight-line code and hipcc retires them with counted s_waitcnt vmcnt(N).
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  auto uniform_ptr = [](const unsigned char* q) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<unsigned char*>(((unsigned long long)hi << 32) | lo);
+  };
+  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<unsigned char*>(inb) + ((long long)in_base * a.in_cs + a.in_coff) * ES), 0, 0x7FFFFFF0, 0x00020000);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<unsigned char*>(wb)), 0, 0x7FFFFFF0, 0x00020000);
+  auto bload = [](decltype(rs_in) rs, unsigned off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  };
+
+  // per-thread staging slots: which vector each of this thread's RI + RW registers carries (chunk independent part)
+  unsigned isrc[RI];           // byte offset of the pixel record relative to the resource base (OOB: zero fill)
   int ivec[RI];                // vector index inside the chunk
 #pragma unroll
   for (int i = 0; i < RI; ++i) {
     const int idx = tid + i * 256;
-    isrc[i] = -1; ivec[i] = 0;
+    isrc[i] = OOB; ivec[i] = 0;
     if (idx < G::NVI) {
       const int hp = idx / VPP;
       ivec[i] = idx % VPP;
-      long long gp;
+      long long rel;
       bool ok;
       if (KS == 1) {
-        gp = in_base + hp;
-        ok = gp < a.total_px;
+        rel = hp;
+        ok = in_base + hp < a.total_px;
       } else {
         const int hy = hp / HW, hx = hp - hy * HW;
         const int iy = iy0 + hy, ix = ix0 + hx;
         ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-        gp = in_base + (long long)(iy >> a.up) * Wi + (ix >> a.up);
+        rel = (long long)(iy >> a.up) * Wi + (ix >> a.up);
       }
-      if (ok) isrc[i] = ((long long)gp * a.in_cs + a.in_coff) * ES;
+      if (ok) isrc[i] = (unsigned)(rel * a.in_cs * ES);
     }
   }
-  long long wsrc[RW];          // byte offset of the fragment row start for k-group 0 (-1: no such slot)
+  unsigned wsrc[RW];           // byte offset of the fragment row start for k-group 0 (OOB: no such slot)
   int wkg[RW];
 #pragma unroll
   for (int i = 0; i < RW; ++i) {
     const int idx = tid + i * 256;
-    wsrc[i] = -1; wkg[i] = 0;
+    wsrc[i] = OOB; wkg[i] = 0;
     if (idx < G::NVW) {
       const int fl = idx / VPF, l = idx % VPF;
       const int kg = fl % KCG, tap = (fl / KCG) % TAPS, ntl = fl / (KCG * TAPS);
       const int nt = min(nblk * NTB + ntl, a.ntiles32 - 1);
       wkg[i] = kg;
-      wsrc[i] = ((long long)(nt * TAPS + tap) * a.ncg) * WFRAG + l * 16;
+      wsrc[i] = (unsigned)(((long long)(nt * TAPS + tap) * a.ncg) * WFRAG + l * 16);
     }
   }
 
-  uint4 ri[RI], rw[RW];
-  auto fetch = [&](int c0) {
+  constexpr int D = G::DEPTH;
+  uint4 ri[D][RI], rw[D][RW];                      // D chunks in flight (static indexing: every loop over D is unrolled)
+  auto fetch = [&](int c0, uint4 (&qi)[RI], uint4 (&qw)[RW]) {
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
       const int c = c0 + ivec[i] * EPV;
-      if (isrc[i] >= 0 && c < a.cin) v = *reinterpret_cast<const uint4*>(inb + isrc[i] + (long long)c * ES);
-      ri[i] = v;
+      qi[i] = bload(rs_in, (isrc[i] != OOB && c < a.cin) ? isrc[i] + (unsigned)(c * ES) : OOB);
     }
     const int cg0 = c0 / KG;
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (wsrc[i] >= 0 && cg0 + wkg[i] < a.ncg) v = *reinterpret_cast<const uint4*>(wb + wsrc[i] + (long long)(cg0 + wkg[i]) * WFRAG);
-      rw[i] = v;
-    }
+    for (int i = 0; i < RW; ++i)
+      qw[i] = bload(rs_w, (wsrc[i] != OOB && cg0 + wkg[i] < a.ncg) ? wsrc[i] + (unsigned)((cg0 + wkg[i]) * WFRAG) : OOB);
   };
-  auto stash = [&](unsigned char* buf) {
+  auto stash = [&](unsigned char* buf, const uint4 (&qi)[RI], const uint4 (&qw)[RW]) {
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
       const int idx = tid + i * 256;
       if (idx < G::NVI) {
         if (SPLIT) {   // 4 floats -> 4 fp16 hi parts + 4 fp16 residuals, stored in the hi / lo halves of the pixel record
-          const float f[4] = {__uint_as_float(ri[i].x), __uint_as_float(ri[i].y), __uint_as_float(ri[i].z), __uint_as_float(ri[i].w)};
+          const float f[4] = {__uint_as_float(qi[i].x), __uint_as_float(qi[i].y), __uint_as_float(qi[i].z), __uint_as_float(qi[i].w)};
           union { uint2 u; _Float16 h[4]; } hi, lo;
 #pragma unroll
           for (int q = 0; q < 4; ++q) { hi.h[q] = (_Float16)f[q]; lo.h[q] = (_Float16)(f[q] - (float)hi.h[q]); }
@@ -257,14 +274,14 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
           *reinterpret_cast<uint2*>(rec) = hi.u;
           *reinterpret_cast<uint2*>(rec + KC * 2) = lo.u;
         } else {
-          *reinterpret_cast<uint4*>(buf + (idx / VPP) * PS + (idx % VPP) * 16) = ri[i];
+          *reinterpret_cast<uint4*>(buf + (idx / VPP) * PS + (idx % VPP) * 16) = qi[i];
         }
       }
     }
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       const int idx = tid + i * 256;
-      if (idx < G::NVW) *reinterpret_cast<uint4*>(buf + G::IN_BYTES + idx * 16) = rw[i];
+      if (idx < G::NVW) *reinterpret_cast<uint4*>(buf + G::IN_BYTES + idx * 16) = qw[i];
     }
   };
 
@@ -284,14 +301,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
     for (int g = 0; g < 4; ++g)
       bias_r[ni][g] = *reinterpret_cast<const float4*>(a.bias + min(ntile0 + ni, a.ntiles32 - 1) * 32 + 8 * g + 4 * hh);
 
-  fetch(0);
-  stash(smem);
-  __syncthreads();
-  int cur = 0;
-  for (int c0 = 0; c0 < a.cin; c0 += KC) {
-    const bool more = c0 + KC < a.cin;
-    if (more && !(a.dbg & 4)) fetch(c0 + KC);              // in flight while this chunk is multiplied
-    const unsigned char* sb = smem + cur * G::BUF;
+  auto compute = [&](const unsigned char* sb, int c0) {
     const unsigned char* sw = sb + G::IN_BYTES + ((wn * NIW) * TAPS * KCG) * WFRAG + lane * 16;
     const int kmax = min(KC, a.cin_pad - c0) / KG;
 #pragma unroll
@@ -330,9 +340,29 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
         }
       }
     }
-    if (more && !(a.dbg & 8)) stash(smem + (cur ^ 1) * G::BUF);   // the other stage was last read one barrier ago
-    __syncthreads();
-    cur ^= 1;
+  };
+
+  // prologue: D chunks requested back to back, the first one moved into LDS stage 0
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d * KC < a.cin && (d == 0 || !(a.dbg & 4))) fetch(d * KC, ri[d], rw[d]);
+  stash(smem, ri[0], rw[0]);
+  __syncthreads();
+  int cur = 0;
+  for (int cb = 0; cb < a.cin; cb += D * KC) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int c0 = cb + d * KC;
+      if (c0 < a.cin) {                                              // block-uniform
+        // register set d carried chunk c0, which already sits in LDS stage `cur`: refill it D chunks ahead
+        if (c0 + D * KC < a.cin && !(a.dbg & 4)) fetch(c0 + D * KC, ri[d], rw[d]);
+        compute(smem + cur * G::BUF, c0);
+        // chunk c0 + KC was requested D - 1 iterations ago: move it into the other stage (last read one barrier ago)
+        if (c0 + KC < a.cin && !(a.dbg & 8)) stash(smem + (cur ^ 1) * G::BUF, ri[(d + 1) % D], rw[(d + 1) % D]);
+        __syncthreads();
+        cur ^= 1;
+      }
+    }
   }
 
   // ---- epilogue A (aligned outputs): transpose each 32 px x 32 ch accumulator tile through a wave-private LDS tile so
@@ -345,6 +375,10 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
     constexpr int LPP = 32 / CPL;                     // lanes per pixel row (8 / 4)
     constexpr int PPI = 64 / LPP;                     // pixels per store instruction (8 / 16)
     unsigned char* et = smem + wave * (32 * EROW);
+    const unsigned char* r1b = a.res1 ? reinterpret_cast<const unsigned char*>(a.res1) + ((long long)out_base * a.r1_cs + a.r1_coff) * ES : wb;
+    const unsigned char* r2b = a.res2 ? reinterpret_cast<const unsigned char*>(a.res2) + ((long long)out_base * a.r2_cs + a.r2_coff) * ES : wb;
+    const auto rs_r1 = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<unsigned char*>(r1b)), 0, 0x7FFFFFF0, 0x00020000);
+    const auto rs_r2 = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<unsigned char*>(r2b)), 0, 0x7FFFFFF0, 0x00020000);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int f = wm * MI + mi;
@@ -370,10 +404,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
           }
           oks[it] = oks[it] && nt * 32 + ch0 < a.cout;
           r1v[it] = make_uint4(0u, 0u, 0u, 0u); r2v[it] = r1v[it];
-          if (oks[it] && a.res1)
-            r1v[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const GT*>(a.res1) + (size_t)gps[it] * a.r1_cs + a.r1_coff + nt * 32 + ch0);
-          if (oks[it] && a.res2)
-            r2v[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const GT*>(a.res2) + (size_t)gps[it] * a.r2_cs + a.r2_coff + nt * 32 + ch0);
+          const unsigned rel_px = (unsigned)(gps[it] - out_base);           // pixel index inside this workgroup's image / run
+          if (a.res1) r1v[it] = bload(rs_r1, oks[it] ? (rel_px * a.r1_cs + nt * 32 + ch0) * ES : OOB);      // uniform branch, branch-free lanes
+          if (a.res2) r2v[it] = bload(rs_r2, oks[it] ? (rel_px * a.r2_cs + nt * 32 + ch0) * ES : OOB);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // previous tile's staging reads have landed in registers
 #pragma unroll
