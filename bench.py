@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--pp-type", default="GREEDYNMM")
     ap.add_argument("--conf", type=float, default=0.5)
     ap.add_argument("--distinct-frames", type=int, default=2)
+    ap.add_argument("--sr-batch-frames", type=int, default=1,
+                    help="frames whose crops are enhanced together as one ragged Real-ESRGAN batch (1: per frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -134,10 +136,11 @@ def main():
     sizes = pipeline.sr_crop_sizes(max(args.sr_crops, 1), seed=0)
     host_rows = torch.empty((cfg.merge_cap, pipe.stride), dtype=torch.float32).pin_memory()
     sr_bytes = int(sum(((int(s) * 4) ** 2 * 3 + 15) // 16 * 16 for s in sizes[:args.sr_crops]))
-    host_sr = torch.empty((max(sr_bytes, 16),), dtype=torch.uint8).pin_memory()
+    host_sr = torch.empty((max(sr_bytes, 16) * max(args.sr_batch_frames, 1),), dtype=torch.uint8).pin_memory()
     state = {}
 
-    pending = {}     # super-resolution of the previous frame still running on the enhancer's stream
+    pending = {}     # super-resolution batch still running on the enhancer's stream
+    queue = []       # (frame tensor, crop boxes) of frames waiting for their SR batch
 
     def drain_sr():
         if pending:
@@ -145,8 +148,17 @@ def main():
             out = pending.pop("out")
             host_sr[:out.numel()].copy_(out)                       # enhanced crops -> host
 
+    def flush_sr(slot):
+        """Enhance the queued frames' crops as ONE ragged batch (asynchronously, on the enhancer's stream)."""
+        if not queue:
+            return
+        drain_sr()
+        out, offs = pipe.enhance_crops_multi([q[0] for q in queue], H, W, [q[1] for q in queue], slot=slot)
+        pending["out"] = out
+        queue.clear()
+
     def step(i, profile=False):
-        """Frame i: detect + merge (detector stream) while frame i-1's crops are still being enhanced (enhancer stream)."""
+        """Frame i: detect + merge on the detector stream while earlier frames' crops are still being enhanced."""
         sf = supers[i % len(supers)]
         if profile:
             pipe.det.set_profile(True)
@@ -163,11 +175,11 @@ def main():
             if args.sr_crops > 0:
                 boxes = pipeline.crop_boxes_for_sr(rows, H, W, args.sr_crops, sizes, seed=i)
                 state["boxes"] = boxes
-                drain_sr()
-                if profile:
-                    pipe.sr.set_profile(True)
-                out, offs = pipe.enhance_crops(sf[f * H:(f + 1) * H], H, W, boxes, wait=False, slot=i & 1)
-                pending["out"] = out
+                queue.append((sf[f * H:(f + 1) * H], boxes))
+                if len(queue) >= args.sr_batch_frames or profile:
+                    if profile:
+                        pipe.sr.set_profile(True)
+                    flush_sr(slot=(i // max(args.sr_batch_frames, 1)) & 1)
         if profile:
             drain_sr()
             torch.cuda.synchronize(dev)
@@ -183,12 +195,14 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    flush_sr(slot=0)
     drain_sr()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, profile=(i == args.steps - 1))      # the last timed step also brackets every conv launch with HIP events
-    drain_sr()                                      # the last frame's crops are part of the timed work
+    flush_sr(slot=0)
+    drain_sr()                                      # the last frames' crops are part of the timed work
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -229,7 +243,7 @@ def main():
                                    f"({items_per_frame - 1} slices + full frame), net input {args.imgsz}, conf {args.conf}, NMS 0.7, "
                                    f"{args.pp_type}/IOS/0.5 merge" + (f", Real-ESRGAN x4 on {args.sr_crops} crops/frame "
                                    f"({int((sizes[:args.sr_crops] ** 2).sum())} px)" if args.sr_crops > 0 else ", no SR"),
-                       "frames_per_step": B, "parallelism": f"items sharded over {world} rank(s), 1 all-gather" if world > 1 else "single GPU",
+                       "frames_per_step": B, "sr_batch_frames": args.sr_batch_frames, "parallelism": f"items sharded over {world} rank(s), 1 all-gather" if world > 1 else "single GPU",
                        "detections_last_frame": int(state.get("rows", np.zeros((0, 1))).shape[0])},
             "stage_ms_last_call": {k: round(v, 3) for k, v in stage_ms.items()},
             "sr_ms_last_call": round(pipe.sr.last_ms(), 3) if pipe.sr is not None else None,

@@ -78,6 +78,8 @@ _SIGS = {
     "ffp_sr_enhance_crops_dev_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _p(C.c_int32), C.c_int, C.c_void_p, C.c_size_t,
                                                  _p(C.c_int64)]),
     "ffp_sr_wait": (C.c_int, [C.c_void_p]),
+    "ffp_sr_enhance_crops_multi_dev_async": (C.c_int, [C.c_void_p, C.c_int, _p(C.c_void_p), _p(C.c_int32), C.c_int, C.c_int, _p(C.c_int32),
+                                                       C.c_int, C.c_void_p, C.c_size_t, _p(C.c_int64)]),
     "ffp_sr_last_ms": (C.c_int, [C.c_void_p, _p(C.c_float)]),
     "ffp_sr_last_conv_stats": (C.c_int, [C.c_void_p, _p(C.c_double), _p(C.c_float), _p(C.c_int32)]),
     "ffp_sr_set_profile": (C.c_int, [C.c_void_p, C.c_int]),

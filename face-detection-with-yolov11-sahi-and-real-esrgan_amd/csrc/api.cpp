@@ -331,10 +331,11 @@ int ffp_sr_enhance(ffp_sr* s, const uint8_t* bgr, int h, int w, int tile, int ti
   return ffp_sr_enhance_batch(s, 1, ins, hs, ws, tile, tile_pad, pre_pad, outs);
 }
 
-static int sr_crops_impl(ffp_sr* s, const uint8_t* d_frame, int H, int W, const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap,
-                         int64_t* out_offsets, bool wait) {
+// crops of one or several resident frames (frame_of_box == nullptr: all from d_frames[0]) -> one ragged SR batch
+static int sr_crops_impl(ffp_sr* s, int n_frames, const uint8_t* const* d_frames, const int32_t* frame_of_box, int H, int W,
+                         const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap, int64_t* out_offsets, bool wait) {
   FFP_API_BEGIN
-  FFP_CHECK(s && d_frame && boxes && n > 0 && d_out && out_offsets, FFP_ERR_ARG, "bad argument");
+  FFP_CHECK(s && d_frames && n_frames > 0 && boxes && n > 0 && d_out && out_offsets, FFP_ERR_ARG, "bad argument");
   SrEngine& e = s->eng;
   FFP_HIP(hipSetDevice(e.device()));
   e.wait_done();                      // one enhancement in flight per handle: its scratch and plan tables are about to be reused
@@ -344,6 +345,8 @@ static int sr_crops_impl(ffp_sr* s, const uint8_t* d_frame, int H, int W, const 
   std::vector<long long> offs(n);
   size_t in_tot = 0, out_tot = 0;
   for (int i = 0; i < n; ++i) {
+    const int fi = frame_of_box ? frame_of_box[i] : 0;
+    FFP_CHECK(fi >= 0 && fi < n_frames && d_frames[fi], FFP_ERR_ARG, "crop %d refers to frame %d of %d", i, fi, n_frames);
     // utils/visualization.py:204-213: int box, clamp to the frame, skip empty
     int x1 = std::max(0, boxes[4 * i]), y1 = std::max(0, boxes[4 * i + 1]);
     int x2 = std::min(W, boxes[4 * i + 2]), y2 = std::min(H, boxes[4 * i + 3]);
@@ -364,7 +367,15 @@ static int sr_crops_impl(ffp_sr* s, const uint8_t* d_frame, int H, int W, const 
   e.scratch_offs.ensure(sizeof(long long) * n);
   FFP_HIP(hipMemcpyAsync(e.scratch_boxes.p, hb.data(), sizeof(int4) * n, hipMemcpyHostToDevice, e.stream()));
   FFP_HIP(hipMemcpyAsync(e.scratch_offs.p, offs.data(), sizeof(long long) * n, hipMemcpyHostToDevice, e.stream()));
-  launch_crop_gather(d_frame, W, e.scratch_boxes.as<int4>(), e.scratch_offs.as<long long>(), n, e.scratch_in.as<uint8_t>(), e.stream());
+  // boxes are gathered frame by frame (contiguous runs of equal frame index)
+  for (int i0 = 0; i0 < n;) {
+    const int fi = frame_of_box ? frame_of_box[i0] : 0;
+    int i1 = i0 + 1;
+    while (i1 < n && (frame_of_box ? frame_of_box[i1] : 0) == fi) ++i1;
+    launch_crop_gather(d_frames[fi], W, e.scratch_boxes.as<int4>() + i0, e.scratch_offs.as<long long>() + i0, i1 - i0,
+                       e.scratch_in.as<uint8_t>(), e.stream());
+    i0 = i1;
+  }
   FFP_HIP(hipStreamSynchronize(e.stream()));
   e.enhance_dev(e.scratch_in.as<uint8_t>(), d_out, v, 0, 10, 0, wait);
   FFP_API_END
@@ -372,12 +383,17 @@ static int sr_crops_impl(ffp_sr* s, const uint8_t* d_frame, int H, int W, const 
 
 int ffp_sr_enhance_crops_dev(ffp_sr* s, const uint8_t* d_frame, int H, int W, const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap,
                              int64_t* out_offsets) {
-  return sr_crops_impl(s, d_frame, H, W, boxes, n, d_out, out_cap, out_offsets, true);
+  return sr_crops_impl(s, 1, &d_frame, nullptr, H, W, boxes, n, d_out, out_cap, out_offsets, true);
 }
 
 int ffp_sr_enhance_crops_dev_async(ffp_sr* s, const uint8_t* d_frame, int H, int W, const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap,
                                    int64_t* out_offsets) {
-  return sr_crops_impl(s, d_frame, H, W, boxes, n, d_out, out_cap, out_offsets, false);
+  return sr_crops_impl(s, 1, &d_frame, nullptr, H, W, boxes, n, d_out, out_cap, out_offsets, false);
+}
+
+int ffp_sr_enhance_crops_multi_dev_async(ffp_sr* s, int n_frames, const uint8_t* const* d_frames, const int32_t* frame_of_box, int H, int W,
+                                         const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap, int64_t* out_offsets) {
+  return sr_crops_impl(s, n_frames, d_frames, frame_of_box, H, W, boxes, n, d_out, out_cap, out_offsets, false);
 }
 
 int ffp_sr_wait(ffp_sr* s) {

@@ -176,5 +176,19 @@ class FramePipeline:
                                                         offs.ctypes.data_as(C.POINTER(C.c_int64))))
         return out, offs
 
+    def enhance_crops_multi(self, d_frames, H: int, W: int, boxes_per_frame, slot: int = 0):
+        """Crops of several resident frames as ONE ragged SR batch (async; wait_sr() before reading)."""
+        torch = self.torch
+        boxes = np.ascontiguousarray(np.concatenate(boxes_per_frame, 0), np.int32)
+        fidx = np.ascontiguousarray(np.concatenate([np.full(len(b), i, np.int32) for i, b in enumerate(boxes_per_frame)]))
+        n = boxes.shape[0]
+        tot = int(sum(((int(b[3] - b[1]) * 4) * (int(b[2] - b[0]) * 4) * 3 + 15) // 16 * 16 for b in boxes))
+        out = self._buf(f"sr_out{slot}", (tot,), torch.uint8)
+        offs = np.zeros(n + 1, np.int64)
+        ptrs = (C.c_void_p * len(d_frames))(*[t.data_ptr() for t in d_frames])
+        _lib._check(_lib.lib().ffp_sr_enhance_crops_multi_dev_async(self.sr.handle, len(d_frames), ptrs, _lib._ip(fidx), H, W, _lib._ip(boxes), n,
+                                                                    out.data_ptr(), tot, offs.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out, offs
+
     def wait_sr(self):
         _lib._check(_lib.lib().ffp_sr_wait(self.sr.handle))

@@ -181,6 +181,11 @@ int ffp_sr_enhance_crops_dev(ffp_sr* s, const uint8_t* d_frame_bgr, int H, int W
 int ffp_sr_enhance_crops_dev_async(ffp_sr* s, const uint8_t* d_frame_bgr, int H, int W, const int32_t* boxes_xyxy, int n,
                                    uint8_t* d_out, size_t out_cap, int64_t* out_offsets);
 int ffp_sr_wait(ffp_sr* s);
+/* Crops of SEVERAL resident frames (all H x W) as one ragged batch: frame_of_box[i] selects d_frames[...] for box i
+ * (boxes of one frame must be contiguous). More pixels per launch = better use of the chip when a frame yields few crops. */
+int ffp_sr_enhance_crops_multi_dev_async(ffp_sr* s, int n_frames, const uint8_t* const* d_frames, const int32_t* frame_of_box,
+                                         int H, int W, const int32_t* boxes_xyxy, int n, uint8_t* d_out, size_t out_cap,
+                                         int64_t* out_offsets);
 
 /* ---------------------------------------------------------------------------------------------------------
  * single-operator entry points (layer-wise parity tests; host NHWC fp32 in/out, computed on `device` in `precision`)
