@@ -227,7 +227,7 @@ def main():
             d = prof[0]
             dtp = d["variant"].split("_")[0]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": f"conv_mfma_kernel<{d['variant']}> ({d['stage']})", "achieved": round(ach, 2),
+            roof = {"bound": "mfma", "kernel": f"{'conv_rows_kernel' if d['variant'].endswith('_rows') else 'conv_mfma_kernel'}<{d['variant']}> ({d['stage']})", "achieved": round(ach, 2),
                     "peak": PEAK_TFLOPS[dtp], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtp], 4),
                     "traffic": (round(pmc[d["variant"]]["hbm_bytes_per_launch"]) if d["variant"] in pmc else None),
                     "traffic_source": ("profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if d["variant"] in pmc else None),

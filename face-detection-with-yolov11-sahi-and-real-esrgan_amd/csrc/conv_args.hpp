@@ -1,0 +1,52 @@
+// conv_args.hpp — kernel argument block and device helpers shared by the MFMA convolution kernels (conv_mfma.hip, conv_rows.hip).
+#pragma once
+#include "ops.hpp"
+
+namespace ffp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvArgs {
+  const void* in;
+  const void* wpk;
+  const float* bias;
+  void* out;
+  const void* res1;
+  const void* res2;
+  const int4* in_tab;
+  const int4* out_tab;
+  const int4* tiles;
+  long long total_px;   // KS == 1: flat pixel count
+  int in_cs, in_coff, cin, cin_pad;
+  int out_cs, out_coff, cout;
+  int r1_cs, r1_coff, r2_cs, r2_coff;
+  float s1, s2;
+  int act, out_f32, up, n_nblk, ncg, ntiles32, vec_ok, fast_out;
+  int force_shape;   // tuning only: -1 auto
+  int dbg;   // tuning only (ffp_op_conv2d_time): 1 skip stores, 2 skip MFMAs, 4 skip chunk refetch, 8 skip LDS stash
+  const void* zeros;   // 256 zero bytes in device memory (padding source of the LDS-DMA loader in conv_rows.hip)
+};
+
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  // blocks b and b+8 share an XCD (observed round-robin dispatch): give each XCD a contiguous run of logical ids.
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  // SiLU with the hardware exp2 / rcp (1 ulp each): ~6 VALU ops instead of ~25 for expf + IEEE divide; the epilogue of a
+  // 256 px x 64 ch block otherwise spends ~2.7 us in the activation alone
+  if (act == ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+  if (act == ACT_LRELU) return v >= 0.f ? v : v * 0.2f;
+  return v;
+}
+
+// host side (conv_mfma.hip)
+ConvArgs make_conv_args(const ConvOp& op);
+// k3 s1 fp16 row-reuse kernel (conv_rows.hip)
+bool conv_rows_eligible(const ConvOp& op, const ConvArgs& a);
+void launch_conv_rows(ConvArgs& a, Level* out_lvl, hipStream_t st);
+void conv_rows_init();
+
+}  // namespace ffp

@@ -13,32 +13,9 @@
 // input tile); the mapping only affects speed.
 #include <type_traits>
 
-#include "ops.hpp"
+#include "conv_args.hpp"
 
 namespace ffp {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-struct ConvArgs {
-  const void* in;
-  const void* wpk;
-  const float* bias;
-  void* out;
-  const void* res1;
-  const void* res2;
-  const int4* in_tab;
-  const int4* out_tab;
-  const int4* tiles;
-  long long total_px;   // KS == 1: flat pixel count
-  int in_cs, in_coff, cin, cin_pad;
-  int out_cs, out_coff, cout;
-  int r1_cs, r1_coff, r2_cs, r2_coff;
-  float s1, s2;
-  int act, out_f32, up, n_nblk, ncg, ntiles32, vec_ok, fast_out;
-  int force_shape;   // tuning only: -1 auto
-  int dbg;   // tuning only (ffp_op_conv2d_time): 1 skip stores, 2 skip MFMAs, 4 skip chunk refetch, 8 skip LDS stash
-};
 
 // fp32 storage with operands split into fp16 hi + lo parts: a*b ~= ah*bh + ah*bl + al*bh (three fp16 MFMAs, fp32
 // accumulate; the dropped al*bl term is 2^-22 relative) — fp32-grade products at 3/16 of the exact-fp32 MFMA time.
@@ -80,20 +57,6 @@ template <> struct MM<X3> {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(uah.h, ubh.h, acc, 0, 0, 0);
   }
 };
-
-__device__ __forceinline__ int xcd_remap(int b, int nwg) {
-  // blocks b and b+8 share an XCD (observed round-robin dispatch): give each XCD a contiguous run of logical ids.
-  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-}
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-  // SiLU with the hardware exp2 / rcp (1 ulp each): ~6 VALU ops instead of ~25 for expf + IEEE divide; the epilogue of a
-  // 256 px x 64 ch block otherwise spends ~2.7 us in the activation alone
-  if (act == ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-  if (act == ACT_LRELU) return v >= 0.f ? v : v * 0.2f;
-  return v;
-}
 
 template <typename T> __device__ __forceinline__ void load4(const T* p, float (&r)[4]);
 template <> __device__ __forceinline__ void load4<float>(const float* p, float (&r)[4]) {
@@ -141,7 +104,14 @@ template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int K
   static constexpr int RI = (NVI + 255) / 256, RW = (NVW + 255) / 256;   // prefetch registers (16 B each) per thread and chunk
   // chunks kept in flight global->registers ahead of the one being multiplied: as many (<= 4) as fit a 2-waves-per-SIMD
   // register budget next to the accumulators. Short chunks (0.25 us of MFMA at KC = 16) need several L2 round trips in flight.
-  static constexpr int DEPTH_RAW = (256 - NIW * MI * 16 - 80 - 3 * (RI + RW)) / (4 * (RI + RW));   // accumulators, ~80 misc, address slots
+  // LDS->register fragment ring of the MFMA loop: a step = one (k-group, tap) = FPS 16-byte fragments; PD steps of lookahead
+  static constexpr int FPS = (MI + NIW) * (std::is_same<T, X3>::value ? 2 : 1);
+  static constexpr int NS = KCG * TAPS;
+  static constexpr int PD_RAW = NIW * MI >= 8 ? 0 : 12 / FPS - 1;     // 128 accumulator registers leave no room for a ring
+  static constexpr int PD_CL = PD_RAW < 0 ? 0 : PD_RAW > 4 ? 4 : PD_RAW;
+  static constexpr int PD = PD_CL > NS - 1 ? NS - 1 : PD_CL;
+  static constexpr int FRAG_REGS = 4 * (PD + 1) * FPS;
+  static constexpr int DEPTH_RAW = (256 - NIW * MI * 16 - 56 - FRAG_REGS - 3 * (RI + RW)) / (4 * (RI + RW));   // accumulators, fragment ring, ~56 misc, address slots
   static constexpr int DEPTH = DEPTH_RAW < 1 ? 1 : DEPTH_RAW > 4 ? 4 : DEPTH_RAW;
   static_assert(KC % KG == 0 && WM * WN == 4, "geometry");
 };
@@ -301,44 +271,46 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
     for (int g = 0; g < 4; ++g)
       bias_r[ni][g] = *reinterpret_cast<const float4*>(a.bias + min(ntile0 + ni, a.ntiles32 - 1) * 32 + 8 * g + 4 * hh);
 
-  auto compute = [&](const unsigned char* sb, int c0) {
+  // One step = one (k-group, tap): MI pixel fragments + NIW weight fragments -> NIW x MI MFMAs. The fragments of step
+  // s + PD are requested from LDS before the MFMAs of step s issue (explicit register ring, everything unrolled): with one
+  // or two waves per SIMD nothing else hides the ~100+ cycle LDS latency, and hipcc on its own schedules each read right
+  // in front of its MFMA (measured: the MFMA phase of the SR body convs ran 3x longer than its MFMA cycles).
+  // A partial last chunk is multiplied in full: its missing channels / k-groups were zero-filled by the loader.
+  constexpr int NS = G::NS, PD = G::PD;
+  constexpr int FB = MI * (SPLIT ? 2 : 1), FA = NIW * (SPLIT ? 2 : 1);
+  auto compute = [&](const unsigned char* sb) {
     const unsigned char* sw = sb + G::IN_BYTES + ((wn * NIW) * TAPS * KCG) * WFRAG + lane * 16;
-    const int kmax = min(KC, a.cin_pad - c0) / KG;
+    uint4 bq[PD + 1][FB], aq[PD + 1][FA];
+    auto ld = [&](int s, int q) {
+      const int ks = s / TAPS, tap = s % TAPS, ky = tap / KS, kx = tap % KS;
 #pragma unroll
-    for (int ks = 0; ks < KCG; ++ks) {
-      if (ks < kmax && !(a.dbg & 2)) {
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-          const int ky = tap / KS, kx = tap % KS;
-          if constexpr (SPLIT) {
-            uint4 bh[MI], bl[MI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-              const unsigned char* bp = sb + boff[mi] + (ky * HW + kx) * PS + ks * LKB;
-              bh[mi] = *reinterpret_cast<const uint4*>(bp);
-              bl[mi] = *reinterpret_cast<const uint4*>(bp + KC * 2);
-            }
-#pragma unroll
-            for (int ni = 0; ni < NIW; ++ni) {
-              const unsigned char* ap = sw + ((ni * TAPS + tap) * KCG + ks) * WFRAG;
-              const uint4 ah = *reinterpret_cast<const uint4*>(ap), al = *reinterpret_cast<const uint4*>(ap + 1024);
-#pragma unroll
-              for (int mi = 0; mi < MI; ++mi) MM<X3>::mma3(acc[ni][mi], ah, al, bh[mi], bl[mi]);
-            }
-          } else {
-            uint4 bf[MI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-              bf[mi] = *reinterpret_cast<const uint4*>(sb + boff[mi] + (ky * HW + kx) * PS + ks * LKB);
-#pragma unroll
-            for (int ni = 0; ni < NIW; ++ni) {
-              const uint4 af = *reinterpret_cast<const uint4*>(sw + ((ni * TAPS + tap) * KCG + ks) * WFRAG);
-#pragma unroll
-              for (int mi = 0; mi < MI; ++mi) MM<T>::mma(acc[ni][mi], af, bf[mi]);
-            }
-          }
-        }
+      for (int mi = 0; mi < MI; ++mi) {
+        const unsigned char* bp = sb + boff[mi] + (ky * HW + kx) * PS + ks * LKB;
+        bq[q][mi] = *reinterpret_cast<const uint4*>(bp);
+        if constexpr (SPLIT) bq[q][MI + mi] = *reinterpret_cast<const uint4*>(bp + KC * 2);
       }
+#pragma unroll
+      for (int ni = 0; ni < NIW; ++ni) {
+        const unsigned char* ap = sw + ((ni * TAPS + tap) * KCG + ks) * WFRAG;
+        aq[q][ni] = *reinterpret_cast<const uint4*>(ap);
+        if constexpr (SPLIT) aq[q][NIW + ni] = *reinterpret_cast<const uint4*>(ap + 1024);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < PD; ++s) { ld(s, s); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (s + PD < NS) ld(s + PD, (s + PD) % (PD + 1));
+      if constexpr (PD > 0) __builtin_amdgcn_sched_barrier(0);        // keep the reads above ahead of this step's MFMAs (the scheduler otherwise sinks them)
+      const int q = s % (PD + 1);
+#pragma unroll
+      for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          if constexpr (SPLIT) MM<X3>::mma3(acc[ni][mi], aq[q][ni], aq[q][NIW + ni], bq[q][mi], bq[q][MI + mi]);
+          else MM<T>::mma(acc[ni][mi], aq[q][ni], bq[q][mi]);
+        }
+      if constexpr (PD > 0) __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -356,7 +328,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
       if (c0 < a.cin) {                                              // block-uniform
         // register set d carried chunk c0, which already sits in LDS stage `cur`: refill it D chunks ahead
         if (c0 + D * KC < a.cin && !(a.dbg & 4)) fetch(c0 + D * KC, ri[d], rw[d]);
-        compute(smem + cur * G::BUF, c0);
+        if (!(a.dbg & 2)) compute(smem + cur * G::BUF);
         // chunk c0 + KC was requested D - 1 iterations ago: move it into the other stage (last read one barrier ago)
         if (c0 + KC < a.cin && !(a.dbg & 8)) stash(smem + (cur ^ 1) * G::BUF, ri[(d + 1) % D], rw[(d + 1) % D]);
         __syncthreads();
@@ -644,16 +616,32 @@ template <typename T> void launch_t(ConvArgs& a, int k, int stride, Level* out_l
 
 }  // namespace
 
+// 256 zero bytes per device: where the LDS-DMA loader of conv_rows.hip reads conv zero padding from
+static const void* zero_block() {
+  static std::map<int, DevBuf> blocks;
+  int dev = 0;
+  FFP_HIP(hipGetDevice(&dev));
+  auto it = blocks.find(dev);
+  if (it == blocks.end()) {
+    DevBuf b(256);
+    FFP_HIP(hipMemset(b.p, 0, 256));
+    it = blocks.emplace(dev, std::move(b)).first;
+  }
+  return it->second.p;
+}
+
 void conv_kernels_init() {
+  (void)zero_block();
   static bool done = false;
   if (done) return;
+  conv_rows_init();
   Family<float, 1, 1>::init(); Family<float, 3, 1>::init(); Family<float, 3, 2>::init();
   Family<_Float16, 1, 1>::init(); Family<_Float16, 3, 1>::init(); Family<_Float16, 3, 2>::init();
   Family<X3, 1, 1>::init(); Family<X3, 3, 1>::init(); Family<X3, 3, 2>::init();
   done = true;
 }
 
-static ConvArgs make_args(const ConvOp& op) {
+ConvArgs make_conv_args(const ConvOp& op) {
   const PackedConv& pc = *op.pc;
   FFP_CHECK(!pc.depthwise(), FFP_ERR_ARG, "conv %s: depthwise goes through launch_dwconv", pc.name.c_str());
   FFP_CHECK(op.in.dt == pc.dt, FFP_ERR_ARG, "conv %s: input dtype differs from packed weights", pc.name.c_str());
@@ -696,6 +684,7 @@ static ConvArgs make_args(const ConvOp& op) {
   }
   a.dbg = op.dbg;
   a.force_shape = op.force_shape;
+  a.zeros = zero_block();
   if (pc.k == 1) FFP_CHECK(op.in.lvl->total_px == op.out.lvl->total_px, FFP_ERR_ARG, "conv %s: 1x1 levels differ", pc.name.c_str());
   return a;
 }
@@ -703,7 +692,8 @@ static ConvArgs make_args(const ConvOp& op) {
 void launch_conv(const ConvOp& op, hipStream_t st) {
   const PackedConv& pc = *op.pc;
   if (conv_direct_eligible(op)) { launch_conv_direct(op, st); return; }
-  ConvArgs a = make_args(op);
+  ConvArgs a = make_conv_args(op);
+  if (conv_rows_eligible(op, a)) { launch_conv_rows(a, op.out.lvl, st); FFP_HIP(hipGetLastError()); return; }
   if (pc.dt == F16) launch_t<_Float16>(a, pc.k, op.stride, op.out.lvl, st);
   else if (pc.split) launch_t<X3>(a, pc.k, op.stride, op.out.lvl, st);
   else launch_t<float>(a, pc.k, op.stride, op.out.lvl, st);
@@ -713,7 +703,8 @@ void launch_conv(const ConvOp& op, hipStream_t st) {
 std::string conv_variant(const ConvOp& op) {
   const PackedConv& pc = *op.pc;
   if (conv_direct_eligible(op)) return std::string(pc.dt == F32 ? "f32" : "f16") + "_k3_direct";
-  const ConvArgs a = make_args(op);
+  const ConvArgs a = make_conv_args(op);
+  if (conv_rows_eligible(op, a)) return "f16_k3s1_rows";
   const int shape = pc.dt == F16 ? choose_t<_Float16>(a, pc.k, op.stride, op.out.lvl)
                     : pc.split ? choose_t<X3>(a, pc.k, op.stride, op.out.lvl) : choose_t<float>(a, pc.k, op.stride, op.out.lvl);
   char buf[64];

@@ -53,6 +53,11 @@ CASES = [
     (1, 33, 47, 3, 32, 3, 2, 1, 0, False),      # image-input convs: direct VALU kernel
     (2, 16, 16, 3, 64, 3, 1, 2, 0, False),
     (1, 20, 20, 3, 16, 3, 2, 1, 0, False),
+    (3, 41, 42, 128, 32, 3, 1, 2, 0, False),    # ESRGAN dense-block shapes: fp16 takes the row-reuse kernel (conv_rows.hip)
+    (2, 52, 33, 96, 32, 3, 1, 2, 0, True),
+    (1, 96, 96, 192, 64, 3, 1, 0, 0, True),
+    (2, 17, 16, 64, 64, 3, 1, 2, 1, False),
+    (1, 1, 1, 64, 32, 3, 1, 2, 0, False),
 ]
 
 

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ffp_amd  # noqa
 from ffp_amd import _lib
-SH = ["wide", "wideH", "narrow2", "narrow2H", "narrow1", "narrow1H"]
+SH = ["wide", "wideH", "narrow2", "narrow2H", "narrow1", "narrow1H", "rows2st", "rows3st"]
 cases = [
     # name, precision, n,h,w,cin,cout,k,s
     ("sr conv1 64->32 (32 crops 48^2-ish)", _lib.PREC_F16, 32, 41, 42, 64, 32, 3, 1),
@@ -16,7 +16,7 @@ cases = [
 ]
 for name, prec, n, h, w, cin, cout, k, s in cases:
     print("==", name)
-    for shape in range(-1, 6):
+    for shape in range(-1, 8):
         try:
             t = _lib.op_conv2d_time(n, h, w, cin, cout, k, s, False, prec, 30, 0, shape)
         except Exception as e:
