@@ -41,7 +41,7 @@ def _compile(src: str, force: bool) -> str:
     spath = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(spath), _newest_header()):
         return obj
-    cmd = [_hipcc(), *FLAGS, "-c", spath, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *os.environ.get("FFP_EXTRA_FLAGS", "").split(), "-c", spath, "-o", obj]
     if src.endswith(".cpp"):
         cmd.insert(1, "-x")
         cmd.insert(2, "hip")

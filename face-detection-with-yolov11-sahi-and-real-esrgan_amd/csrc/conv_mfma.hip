@@ -15,6 +15,10 @@
 
 #include "conv_args.hpp"
 
+#ifndef FFP_DEEP_OCC1
+#define FFP_DEEP_OCC1 0      // tuning switch: 1 = shapes whose LDS allows one workgroup per CU get 512 registers and a deeper prefetch ring (measured: no gain)
+#endif
+
 namespace ffp {
 
 // fp32 storage with operands split into fp16 hi + lo parts: a*b ~= ah*bh + ah*bl + al*bh (three fp16 MFMAs, fp32
@@ -111,7 +115,11 @@ template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int K
   static constexpr int PD_CL = PD_RAW < 0 ? 0 : PD_RAW > 4 ? 4 : PD_RAW;
   static constexpr int PD = PD_CL > NS - 1 ? NS - 1 : PD_CL;
   static constexpr int FRAG_REGS = 4 * (PD + 1) * FPS;
-  static constexpr int DEPTH_RAW = (256 - NIW * MI * 16 - 56 - FRAG_REGS - 3 * (RI + RW)) / (4 * (RI + RW));   // accumulators, fragment ring, ~56 misc, address slots
+  // a shape whose LDS footprint allows one workgroup per CU anyway gets the whole 512-register file (launch bound 1 wave
+  // per SIMD) and spends it on prefetch depth: with D = 1 every chunk of an HBM-fed layer exposes a full memory round trip
+  static constexpr int OCC = (LDS <= 80 * 1024 || !FFP_DEEP_OCC1) ? 2 : 1;
+  static constexpr int REG_BUDGET = OCC == 2 ? 256 : 448;
+  static constexpr int DEPTH_RAW = (REG_BUDGET - NIW * MI * 16 - 56 - FRAG_REGS - 3 * (RI + RW)) / (4 * (RI + RW));   // accumulators, fragment ring, ~56 misc, address slots
   static constexpr int DEPTH = DEPTH_RAW < 1 ? 1 : DEPTH_RAW > 4 ? 4 : DEPTH_RAW;
   static_assert(KC % KG == 0 && WM * WN == 4, "geometry");
 };
@@ -120,7 +128,7 @@ template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int K
 // chunk c+1 is fetched global->registers while chunk c is multiplied out of LDS (no global access inside the MFMA
 // loop), then written to the other stage: one barrier per chunk.
 template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int KC>
-__global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>::OCC)) conv_mfma_kernel(const ConvArgs a) {
   using G = Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>;
   using GT = typename G::GT;
   constexpr bool SPLIT = std::is_same<T, X3>::value;

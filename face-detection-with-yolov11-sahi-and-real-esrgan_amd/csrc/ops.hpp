@@ -60,4 +60,8 @@ struct LetterboxImg {     // one network input image cut from the frame
 void launch_letterbox(const uint8_t* d_frame, int H, int W, int flip, const DevBuf& d_imgs /*LetterboxImg[n]*/,
                       const TView& out, hipStream_t st);
 
+// the image-input conv (YOLO stem) reading the u8 frame through the letterbox arithmetic: letterbox + stem in one launch,
+// bit-identical to launch_letterbox followed by launch_conv_direct (op.in only carries the level and the channel padding)
+void launch_stem_from_frame(const uint8_t* d_frame, int H, int W, int flip, const DevBuf& d_imgs, const ConvOp& op, hipStream_t st);
+
 }  // namespace ffp

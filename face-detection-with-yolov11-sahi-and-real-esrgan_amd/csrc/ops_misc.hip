@@ -250,16 +250,10 @@ __device__ __forceinline__ void lin_coef(int d, double scale, int n_src, bool ze
   c1 = (int)rintf(f * 2048.0f);
 }
 
-template <typename T, int CPAD>
-__global__ void letterbox_kernel(const uint8_t* __restrict__ frame, int W, int flip, const LetterboxImg* __restrict__ imgs,
-                                 const int4* __restrict__ tab, int n_img, T* __restrict__ out, long long total_px) {
-  const long long gp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gp >= total_px) return;
-  const int im = find_img(tab, n_img, gp);
-  const int4 t = tab[im];
-  const LetterboxImg L = imgs[im];
-  const int lp = (int)(gp - t.x), y = lp / t.z, x = lp - y * t.z;
-  int px[3] = {114, 114, 114};
+// One pixel of the letterboxed network image (u8 per channel, source channel order): pad 114 outside the resized picture,
+// a plain copy when the crop is not resized, else the fixed-point bilinear sample.
+__device__ __forceinline__ void letterbox_sample(const uint8_t* __restrict__ frame, int W, const LetterboxImg& L, int y, int x, int (&px)[3]) {
+  px[0] = px[1] = px[2] = 114;
   const int ry = y - L.top, rx = x - L.left;
   if (ry >= 0 && ry < L.new_h && rx >= 0 && rx < L.new_w) {
     const uint8_t* src = frame + ((size_t)L.y0 * W + L.x0) * 3;
@@ -284,11 +278,73 @@ __global__ void letterbox_kernel(const uint8_t* __restrict__ frame, int W, int f
       }
     }
   }
+}
+
+template <typename T, int CPAD>
+__global__ void letterbox_kernel(const uint8_t* __restrict__ frame, int W, int flip, const LetterboxImg* __restrict__ imgs,
+                                 const int4* __restrict__ tab, int n_img, T* __restrict__ out, long long total_px) {
+  const long long gp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gp >= total_px) return;
+  const int im = find_img(tab, n_img, gp);
+  const int4 t = tab[im];
+  const LetterboxImg L = imgs[im];
+  const int lp = (int)(gp - t.x), y = lp / t.z, x = lp - y * t.z;
+  int px[3];
+  letterbox_sample(frame, W, L, y, x, px);
   T* op = out + (size_t)gp * CPAD;
   const float v0 = (float)px[flip ? 2 : 0] / 255.0f, v1 = (float)px[1] / 255.0f, v2 = (float)px[flip ? 0 : 2] / 255.0f;
   stf(op + 0, v0); stf(op + 1, v1); stf(op + 2, v2);
 #pragma unroll
   for (int c = 3; c < CPAD; ++c) stf(op + c, 0.f);
+}
+
+// ---- stem fused with the letterbox: the image-input 3x3 conv reads the u8 frame through letterbox_sample() instead of
+// a letterboxed fp32 copy (61 x 512^2 x 16 B = 256 MB written and read back per 4K frame). Same arithmetic, same order
+// as letterbox_kernel + conv3x3_c3_direct_kernel: results are bit-identical to the two-kernel path.
+template <typename T, int COUT>
+__global__ void __launch_bounds__(256) stem_from_frame_kernel(const uint8_t* __restrict__ frame, int W, int flip, const LetterboxImg* __restrict__ imgs,
+                                                              T* __restrict__ out, int out_cs, int out_coff, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, int stride, int act, const int4* __restrict__ in_tab,
+                                                              const int4* __restrict__ out_tab, int n_img, long long total_out_px) {
+  __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
+  for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = w[i];
+  __syncthreads();
+  const long long gp = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gp >= total_out_px) return;
+  const int im = find_img(out_tab, n_img, gp);
+  const int4 to = out_tab[im], ti = in_tab[im];
+  const LetterboxImg L = imgs[im];
+  const int lp = (int)(gp - to.x), oy = lp / to.z, ox = lp - oy * to.z;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+    float px[3] = {0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)ti.y && (unsigned)ix < (unsigned)ti.z) {
+      int q[3];
+      letterbox_sample(frame, W, L, iy, ix, q);
+      // through T: the two-kernel path stores the normalised pixel in the activation type
+      px[0] = (float)(T)((float)q[flip ? 2 : 0] / 255.0f); px[1] = (float)(T)((float)q[1] / 255.0f); px[2] = (float)(T)((float)q[flip ? 0 : 2] / 255.0f);
+    }
+    const float* wt = ws + tap * 3 * COUT;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int c = 0; c < COUT; c += 4) {
+        const float4 k = *reinterpret_cast<const float4*>(wt + ci * COUT + c);
+        acc[c] = fmaf(px[ci], k.x, acc[c]); acc[c + 1] = fmaf(px[ci], k.y, acc[c + 1]);
+        acc[c + 2] = fmaf(px[ci], k.z, acc[c + 2]); acc[c + 3] = fmaf(px[ci], k.w, acc[c + 3]);
+      }
+  }
+  T* op = out + (size_t)gp * out_cs + out_coff;
+#pragma unroll
+  for (int c = 0; c < COUT; c += 4) {
+    const float4 b = *reinterpret_cast<const float4*>(bias + c);
+    st4<T>(op + c, make_float4(act_fn(acc[c] + b.x, act), act_fn(acc[c + 1] + b.y, act), act_fn(acc[c + 2] + b.z, act), act_fn(acc[c + 3] + b.w, act)));
+  }
 }
 
 inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
@@ -317,6 +373,27 @@ void launch_conv_direct(const ConvOp& op, hipStream_t st) {
     if (pc.cout == 16) launch_direct_t<float, 16>(op, st); else if (pc.cout == 32) launch_direct_t<float, 32>(op, st); else launch_direct_t<float, 64>(op, st);
   } else {
     if (pc.cout == 16) launch_direct_t<_Float16, 16>(op, st); else if (pc.cout == 32) launch_direct_t<_Float16, 32>(op, st); else launch_direct_t<_Float16, 64>(op, st);
+  }
+  FFP_HIP(hipGetLastError());
+}
+
+template <typename T, int COUT>
+static void launch_stem_t(const uint8_t* d_frame, int W, int flip, const DevBuf& d_imgs, const ConvOp& op, hipStream_t st) {
+  const PackedConv& pc = *op.pc;
+  const long long total = op.out.lvl->total_px;
+  hipLaunchKernelGGL((stem_from_frame_kernel<T, COUT>), dim3(blocks_for(total, 256)), dim3(256), 0, st, d_frame, W, flip, d_imgs.as<LetterboxImg>(),
+                     (T*)op.out.ptr, op.out.cs, op.out.coff, pc.w_direct.as<float>(), pc.bias.as<float>(), op.stride, op.act,
+                     op.in.lvl->d_tab.as<int4>(), op.out.lvl->d_tab.as<int4>(), op.out.lvl->n, total);
+}
+
+void launch_stem_from_frame(const uint8_t* d_frame, int H, int W, int flip, const DevBuf& d_imgs, const ConvOp& op, hipStream_t st) {
+  const PackedConv& pc = *op.pc;
+  (void)H;
+  FFP_CHECK(conv_direct_eligible(op), FFP_ERR_ARG, "conv %s: not eligible for the fused stem", pc.name.c_str());
+  if (pc.dt == F32) {
+    if (pc.cout == 16) launch_stem_t<float, 16>(d_frame, W, flip, d_imgs, op, st); else if (pc.cout == 32) launch_stem_t<float, 32>(d_frame, W, flip, d_imgs, op, st); else launch_stem_t<float, 64>(d_frame, W, flip, d_imgs, op, st);
+  } else {
+    if (pc.cout == 16) launch_stem_t<_Float16, 16>(d_frame, W, flip, d_imgs, op, st); else if (pc.cout == 32) launch_stem_t<_Float16, 32>(d_frame, W, flip, d_imgs, op, st); else launch_stem_t<_Float16, 64>(d_frame, W, flip, d_imgs, op, st);
   }
   FFP_HIP(hipGetLastError());
 }

@@ -128,7 +128,8 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
 
   // ---- buffers that realise the Concat layers --------------------------------------------------------------------
   const int cin0 = T == F16 ? 8 : 4;
-  P.input = P.alloc(P.L[0], cin0, T);
+  P.input = TView{};
+  P.input.dt = T; P.input.cs = cin0; P.input.C = cin0; P.input.lvl = P.L[0];     // storage only if the stem is not fused (below)
   TView cat12 = P.alloc(P.L[4], c1024 + c512, T);   // [up(x10) | x6]
   TView cat15 = P.alloc(P.L[3], c512 + c512, T);    // [up(x13) | x4]
   TView cat18 = P.alloc(P.L[4], c256 + c512, T);    // [conv17(x16) | x13]
@@ -138,7 +139,20 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
 
   // ---- backbone --------------------------------------------------------------------------------------------------------
   TView x0 = P.alloc(P.L[1], c64, T);
-  cv("model.0.conv", P.input, x0, 2, ACT_SILU);   // stem reads the 4/8-channel padded image (weights zero padded at pack)
+  {   // stem: fused with the letterbox when the direct image-input kernel applies (always, for 3-channel frames)
+    ConvOp o;
+    o.pc = conv("model.0.conv"); o.in = P.input; o.out = x0; o.stride = 2; o.act = ACT_SILU;
+    FFP_CHECK(o.pc->cin == cin0 && o.pc->cout == c64, FFP_ERR_WEIGHTS, "model.0.conv: weights are %d->%d, graph expects %d->%d", o.pc->cin,
+              o.pc->cout, cin0, c64);
+    if (conv_direct_eligible(o) && !getenv("FFP_NO_FUSED_STEM")) {
+      o.flops = conv_flops_of(*o.pc, x0.lvl->total_px);
+      P.stem = o; P.fused_stem = true;
+      P.conv_flops += o.flops; P.conv_launches += 1;
+    } else {
+      P.input = P.alloc(P.L[0], cin0, T);
+      cv("model.0.conv", P.input, x0, 2, ACT_SILU);   // reads the 4/8-channel padded image (weights zero padded at pack)
+    }
+  }
   TView x1 = P.alloc(P.L[2], c128, T);
   cv("model.1.conv", x0, x1, 2, ACT_SILU);
   TView x2 = P.alloc(P.L[2], c256, T);
@@ -314,7 +328,9 @@ DetPlan* DetEngine::prepare(const uint8_t* d_frame, int H, int W, int chan_order
   FFP_HIP(hipMemcpyAsync(P->d_imgs.p, di.data(), sizeof(DetImg) * n_tiles, hipMemcpyHostToDevice, st_));
   FFP_HIP(hipStreamSynchronize(st_));   // lb/di are stack vectors
   FFP_HIP(hipEventRecord(ev_[0], st_));
-  launch_letterbox(d_frame, H, W, chan_order == FFP_CHAN_AS_BGR ? 1 : 0, P->d_lb, P->input, st_);
+  const int flip = chan_order == FFP_CHAN_AS_BGR ? 1 : 0;
+  if (P->fused_stem) launch_stem_from_frame(d_frame, H, W, flip, P->d_lb, P->stem, st_);
+  else launch_letterbox(d_frame, H, W, flip, P->d_lb, P->input, st_);
   FFP_HIP(hipEventRecord(ev_[1], st_));
   if (prof.enabled) prof.begin();
   P->execute(st_, &prof);

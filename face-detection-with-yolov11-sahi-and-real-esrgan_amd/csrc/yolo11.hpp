@@ -11,6 +11,8 @@ struct DetPlan : Plan {
   std::vector<int> anchor_off;
   DevBuf d_anchor_off, d_boxes, d_scores, d_classes, d_cand, d_cscore, d_lb, d_imgs;
   int total_anchors = 0;
+  ConvOp stem;              // model.0 when it is fused with the letterbox (runs ahead of the captured launch sequence)
+  bool fused_stem = false;
 };
 
 struct TileGeom {       // host-side geometry of one crop

@@ -1,0 +1,73 @@
+"""Aggregate rocprofv3 PMC passes into HBM bytes per launch for each conv kernel variant -> profiles/r01_pmc_traffic.json.
+
+Collection (two separate passes, counters only, as MI355X_MICROARCH.md prescribes):
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o f --output-format csv -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write -o w --output-format csv -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv
+FETCH_SIZE / WRITE_SIZE count KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled.
+"""
+import csv, json, os, re, sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def variant(sym: str):
+    m = re.search(r"conv_rows_kernel<(\d+), *(\d+)>", sym) or re.search(r"conv_rows_kernelILi(\d+)ELi(\d+)E", sym)
+    if m:
+        return "f16_k3s1_rows"
+    m = re.search(r"conv_mfma_kernel<([^,]+), *(\d+), *(\d+), *(\d+), *(\d+), *(\d+), *(\d+), *(\d+)>", sym)
+    if m:
+        t, ks, s, wm, wn, mi, niw, kc = m.group(1), *map(int, m.groups()[1:])
+    else:
+        m = re.search(r"conv_mfma_kernelI(f|DF16_|NS_2X3E)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", sym)
+        if not m:
+            return None
+        t, ks, s, wm, wn, mi, niw, kc = m.group(1), *map(int, m.groups()[1:])
+    dt = "f32x3" if "X3" in t else ("f16" if ("16" in t or "half" in t.lower()) else "f32")
+    full = 2 if s == 2 else 4            # MI of the full-size wide shape; narrow full = full / 2 (>= 1)
+    if wm == 2:
+        shape = "wide" if mi == full else "wideH"
+    else:
+        nfull = max(full // 2, 1)
+        shape = ("narrow2" if niw == 2 else "narrow1") + ("" if mi == nfull else "H")
+    return f"{dt}_k{ks}s{s}_{shape}"
+
+
+def load(path, counter):
+    acc = defaultdict(lambda: [0, 0.0, 0.0, ""])      # launches, counter sum, time sum, symbol
+    with open(path, newline="") as fh:
+        for r in csv.DictReader(fh):
+            if r["Counter_Name"] != counter:
+                continue
+            v = variant(r["Kernel_Name"])
+            if v is None:
+                continue
+            a = acc[v]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+            a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+            a[3] = r["Kernel_Name"]
+    return acc
+
+
+def main():
+    f = load(sys.argv[1], "FETCH_SIZE")
+    w = load(sys.argv[2], "WRITE_SIZE")
+    out = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) over `python bench.py --steps 4 --warmup 2 "
+                      "--no-cpu-baseline`; KiB units x1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced "
+                      "reads); per-launch means; aggregated by tools/pmc_traffic.py", "kernels": {}}
+    for v in sorted(f):
+        n, s, t, sym = f[v]
+        fetch = s / n * 1024 * 2
+        wr = (w[v][1] / w[v][0] * 1024) if v in w and w[v][0] else 0.0
+        out["kernels"][v] = {"launches": n, "avg_us": t / n, "hbm_fetch_bytes_per_launch_x2corrected": fetch, "hbm_write_bytes_per_launch": wr,
+                             "symbol": sym, "hbm_bytes_per_launch": fetch + wr}
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("wrote", path, "with", len(out["kernels"]), "kernel variants")
+
+
+if __name__ == "__main__":
+    main()
