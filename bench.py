@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--pp-type", default="GREEDYNMM")
     ap.add_argument("--conf", type=float, default=0.5)
     ap.add_argument("--distinct-frames", type=int, default=2)
-    ap.add_argument("--sr-batch-frames", type=int, default=1,
+    ap.add_argument("--sr-batch-frames", type=int, default=2,
                     help="frames whose crops are enhanced together as one ragged Real-ESRGAN batch (1: per frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()

@@ -15,7 +15,7 @@ struct ffp_sr { ffp::SrEngine eng; ffp_sr(const void* w, size_t n, int s, int nb
 
 using namespace ffp;
 
-#define FFP_API_BEGIN try {
+#define FFP_API_BEGIN try { ffp::ApiShared gate_share_;
 #define FFP_API_END                                                              \
   return FFP_OK;                                                                 \
   }                                                                              \

@@ -1,6 +1,8 @@
 // engine.cpp — plan bookkeeping and conv-kernel profiling.
 #include "engine.hpp"
 
+#include <shared_mutex>
+
 #include <cstdlib>
 
 namespace ffp {
@@ -77,6 +79,26 @@ void Plan::add_conv(const ConvOp& op) {
   steps.push_back(std::move(s));
 }
 
+namespace {
+std::shared_mutex g_gate;
+thread_local int tl_shared_depth = 0;
+}  // namespace
+
+ApiShared::ApiShared() {
+  if (tl_shared_depth++ == 0) g_gate.lock_shared();
+}
+ApiShared::~ApiShared() {
+  if (--tl_shared_depth == 0) g_gate.unlock_shared();
+}
+CaptureExclusive::CaptureExclusive() {
+  if (tl_shared_depth > 0) g_gate.unlock_shared();
+  g_gate.lock();
+}
+CaptureExclusive::~CaptureExclusive() {
+  g_gate.unlock();
+  if (tl_shared_depth > 0) g_gate.lock_shared();
+}
+
 Plan::~Plan() {
   if (gexec) (void)hipGraphExecDestroy(gexec);
   if (graph) (void)hipGraphDestroy(graph);
@@ -104,6 +126,7 @@ void Plan::execute(hipStream_t st, ConvProfile* prof) {
   if (runs > 0 && graph_ok && graphs_enabled()) {
     if (!gexec) {
       // first eager run has built every lazily created table; capture the identical sequence now
+      CaptureExclusive only_me;
       if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         bool ok = true;
         try {
@@ -113,8 +136,10 @@ void Plan::execute(hipStream_t st, ConvProfile* prof) {
         }
         hipGraph_t g = nullptr;
         if (hipStreamEndCapture(st, &g) != hipSuccess || !ok || !g) {
-          graph_ok = false;
+          graph_ok = ++capture_failures < 3;          // an invalidated capture is retried on a later run, then given up
           if (g) (void)hipGraphDestroy(g);
+          hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+          if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); }
           (void)hipGetLastError();
         } else if (hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0) != hipSuccess) {
           graph_ok = false;

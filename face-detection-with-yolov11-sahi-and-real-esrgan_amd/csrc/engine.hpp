@@ -48,6 +48,7 @@ struct Plan {
   hipGraphExec_t gexec = nullptr;
   int runs = 0;
   bool graph_ok = true;
+  int capture_failures = 0;
   ~Plan();
 
   Level* add_level(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st);
@@ -55,6 +56,19 @@ struct Plan {
   void add_conv(const ConvOp& op);
   void add(std::function<void(hipStream_t)> f) { Step s; s.run = std::move(f); steps.push_back(std::move(s)); }
   void execute(hipStream_t st, ConvProfile* prof);
+};
+
+// Process-wide gate between hipGraph capture and everything else the library does on other host threads: an allocation,
+// a blocking copy or a synchronisation issued by another thread while a stream is being captured can invalidate the
+// capture on ROCm (seen with one host thread per engine). Every C-ABI entry holds the gate shared; a capture trades its
+// share for exclusive ownership (~1 ms, once per plan).
+struct ApiShared {
+  ApiShared();
+  ~ApiShared();
+};
+struct CaptureExclusive {
+  CaptureExclusive();
+  ~CaptureExclusive();
 };
 
 inline double conv_flops_of(const PackedConv& pc, int64_t out_px) {

@@ -112,6 +112,52 @@ __global__ void sppf_pool_kernel(const T* __restrict__ in, int in_cs, int in_cof
   st4<T>(y3 + (size_t)gp * o_cs + o3 + c, m13);
 }
 
+// Small maps (the stride-32 level: 16x16 at 512, 32x32 at 1024): one workgroup = one image x 4 channels, the map lives in
+// LDS and the square windows are separated into a row pass and a column pass (26 LDS reads per pixel instead of 169
+// global reads; max is exact, so the result is identical to the direct kernel above).
+template <typename T>
+__global__ void __launch_bounds__(256) sppf_pool_lds_kernel(const T* __restrict__ in, int in_cs, int in_coff, T* __restrict__ y1, T* __restrict__ y2,
+                                                            T* __restrict__ y3, int o_cs, int o1, int o2, int o3, const int4* __restrict__ tab) {
+  constexpr int MAXPX = 1024;
+  __shared__ float4 sv[MAXPX], r5[MAXPX], r9[MAXPX], r13[MAXPX];
+  const int4 t = tab[blockIdx.y];
+  const int H = t.y, W = t.z, N = H * W, c = blockIdx.x * 4;
+  const float ninf = -INFINITY;
+  for (int i = threadIdx.x; i < N; i += 256) sv[i] = ld4<T>(in + ((size_t)t.x + i) * in_cs + in_coff + c);
+  __syncthreads();
+  auto mx = [](float4& a, const float4& b) { a.x = fmaxf(a.x, b.x); a.y = fmaxf(a.y, b.y); a.z = fmaxf(a.z, b.z); a.w = fmaxf(a.w, b.w); };
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const int y = i / W, x = i - y * W;
+    float4 m5 = make_float4(ninf, ninf, ninf, ninf), m9 = m5, m13 = m5;
+    for (int dx = -6; dx <= 6; ++dx) {
+      const int xx = x + dx;
+      if ((unsigned)xx >= (unsigned)W) continue;
+      const float4 v = sv[y * W + xx];
+      mx(m13, v);
+      if (abs(dx) <= 4) mx(m9, v);
+      if (abs(dx) <= 2) mx(m5, v);
+    }
+    r5[i] = m5; r9[i] = m9; r13[i] = m13;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const int y = i / W, x = i - y * W;
+    float4 m5 = make_float4(ninf, ninf, ninf, ninf), m9 = m5, m13 = m5;
+    for (int dy = -6; dy <= 6; ++dy) {
+      const int yy = y + dy;
+      if ((unsigned)yy >= (unsigned)H) continue;
+      const int j = yy * W + x;
+      mx(m13, r13[j]);
+      if (abs(dy) <= 4) mx(m9, r9[j]);
+      if (abs(dy) <= 2) mx(m5, r5[j]);
+    }
+    const size_t gp = (size_t)t.x + i;
+    st4<T>(y1 + gp * o_cs + o1 + c, m5);
+    st4<T>(y2 + gp * o_cs + o2 + c, m9);
+    st4<T>(y3 + gp * o_cs + o3 + c, m13);
+  }
+}
+
 // ---- nearest x2: one thread copies 16 bytes ---------------------------------------------------------------------------
 __global__ void upsample2x_kernel(const unsigned char* __restrict__ in, int in_cs_b, int in_coff_b, const int4* __restrict__ in_tab,
                                   unsigned char* __restrict__ out, int out_cs_b, int out_coff_b, const int4* __restrict__ out_tab,
@@ -432,6 +478,19 @@ void launch_sppf_pool(const TView& in, const TView& y1, const TView& y2, const T
   const long long total = in.lvl->total_px * (C / 4);
   const unsigned nb = blocks_for(total, 256);
   const int4* tab = in.lvl->d_tab.as<int4>();
+  int max_px = 0;
+  for (int i = 0; i < in.lvl->n; ++i) max_px = std::max(max_px, in.lvl->h[i] * in.lvl->w[i]);
+  if (max_px <= 1024) {
+    const dim3 grid(C / 4, in.lvl->n);
+    if (in.dt == F32)
+      hipLaunchKernelGGL(sppf_pool_lds_kernel<float>, grid, dim3(256), 0, st, (const float*)in.ptr, in.cs, in.coff, (float*)y1.ptr, (float*)y2.ptr,
+                         (float*)y3.ptr, y1.cs, y1.coff, y2.coff, y3.coff, tab);
+    else
+      hipLaunchKernelGGL(sppf_pool_lds_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16*)in.ptr, in.cs, in.coff, (_Float16*)y1.ptr,
+                         (_Float16*)y2.ptr, (_Float16*)y3.ptr, y1.cs, y1.coff, y2.coff, y3.coff, tab);
+    FFP_HIP(hipGetLastError());
+    return;
+  }
   if (in.dt == F32)
     hipLaunchKernelGGL(sppf_pool_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)in.ptr, in.cs, in.coff, (float*)y1.ptr,
                        (float*)y2.ptr, (float*)y3.ptr, y1.cs, y1.coff, y2.coff, y3.coff, C, tab, in.lvl->n, in.lvl->total_px);
