@@ -15,6 +15,9 @@
 
 #include "conv_args.hpp"
 
+#ifndef FFP_SINGLE_STAGE
+#define FFP_SINGLE_STAGE 1     // tuning switch: 0 = always double-buffer the LDS stage
+#endif
 #ifndef FFP_DEEP_OCC1
 #define FFP_DEEP_OCC1 0      // tuning switch: 1 = shapes whose LDS allows one workgroup per CU get 512 registers and a deeper prefetch ring (measured: no gain)
 #endif
@@ -103,7 +106,12 @@ template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int K
   static constexpr int W_FRAGS = NTB * TAPS * KCG;          // weight fragments per chunk
   static constexpr int VPF = WFRAG / 16;                    // 16-byte vectors per weight fragment
   static constexpr int BUF = IN_BYTES + W_FRAGS * WFRAG;    // one LDS stage: input tile chunk + its weights
-  static constexpr int LDS = 2 * BUF;                       // double buffered
+  // Two stages (chunk c+1 is written while chunk c is multiplied) where both fit 80 KiB, i.e. two workgroups per CU. A
+  // shape whose single stage still fits 80 KiB runs ONE stage (two barriers per chunk, no overlap inside the workgroup)
+  // and lets the second resident workgroup fill the CU instead: with one workgroup per CU its fetch, MFMA and store
+  // phases simply add up (measured on the fp32-split 3x3 stride-2 layers).
+  static constexpr int STAGES = (2 * BUF <= 80 * 1024 || BUF > 80 * 1024 || !FFP_SINGLE_STAGE) ? 2 : 1;
+  static constexpr int LDS = STAGES * BUF;
   static constexpr int NVI = NPIX * VPP, NVW = W_FRAGS * VPF;
   static constexpr int RI = (NVI + 255) / 256, RW = (NVW + 255) / 256;   // prefetch registers (16 B each) per thread and chunk
   // chunks kept in flight global->registers ahead of the one being multiplied: as many (<= 4) as fit a 2-waves-per-SIMD
@@ -338,9 +346,15 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
         if (c0 + D * KC < a.cin && !(a.dbg & 4)) fetch(c0 + D * KC, ri[d], rw[d]);
         if (!(a.dbg & 2)) compute(smem + cur * G::BUF);
         // chunk c0 + KC was requested D - 1 iterations ago: move it into the other stage (last read one barrier ago)
-        if (c0 + KC < a.cin && !(a.dbg & 8)) stash(smem + (cur ^ 1) * G::BUF, ri[(d + 1) % D], rw[(d + 1) % D]);
-        __syncthreads();
-        cur ^= 1;
+        if constexpr (G::STAGES == 1) {
+          __syncthreads();                                             // everyone is done reading the only stage
+          if (c0 + KC < a.cin && !(a.dbg & 8)) stash(smem, ri[(d + 1) % D], rw[(d + 1) % D]);
+          __syncthreads();
+        } else {
+          if (c0 + KC < a.cin && !(a.dbg & 8)) stash(smem + (cur ^ 1) * G::BUF, ri[(d + 1) % D], rw[(d + 1) % D]);
+          __syncthreads();
+          cur ^= 1;
+        }
       }
     }
   }
