@@ -588,6 +588,17 @@ template <typename T, int KS, int STRIDE> struct Family {
     const long long tiles = KS == 1 ? (a.total_px + C::BLOCK_PX - 1) / C::BLOCK_PX : out_lvl->count_tiles(C::G::TH);
     return tiles * ((a.ntiles32 * 32 + C::BLOCK_N - 1) / C::BLOCK_N);
   }
+  static unsigned valid_mask(const ConvArgs& a) {
+    const bool wide_ok = a.ntiles32 >= 3 && (KS == 1 || STRIDE == 2);
+    unsigned m = 0;
+    if (Wide::OK && wide_ok) m |= 1u << 0;
+    if (WideH::OK && wide_ok) m |= 1u << 1;
+    if (Narrow2::OK && a.ntiles32 >= 2) m |= 1u << 2;
+    if (HAS_NH && Narrow2H::OK && a.ntiles32 >= 2) m |= 1u << 3;
+    if (Narrow1::OK) m |= 1u << 4;
+    if (HAS_NH && Narrow1H::OK) m |= 1u << 5;
+    return m;
+  }
   static int choose(const ConvArgs& a, Level* out_lvl) {
     // candidates in decreasing block size; first pass: shapes that allow two resident workgroups per CU (LDS <= 80 KiB) and fill the chip; second pass: any shape with enough work; else the shape with the most workgroups.
     constexpr long long ENOUGH = 192;     // >= 3/4 of the 256 CUs get a workgroup: measured better than insisting on two for the SR body convs
@@ -627,6 +638,13 @@ template <typename T> int choose_t(const ConvArgs& a, int k, int stride, Level* 
   if (k == 3 && stride == 1) return Family<T, 3, 1>::choose(a, out_lvl);
   if (k == 3 && stride == 2) return Family<T, 3, 2>::choose(a, out_lvl);
   return 4;
+}
+
+template <typename T> unsigned valid_t(const ConvArgs& a, int k, int stride) {
+  if (k == 1 && stride == 1) return Family<T, 1, 1>::valid_mask(a);
+  if (k == 3 && stride == 1) return Family<T, 3, 1>::valid_mask(a);
+  if (k == 3 && stride == 2) return Family<T, 3, 2>::valid_mask(a);
+  return 0;
 }
 
 template <typename T> void launch_t(ConvArgs& a, int k, int stride, Level* out_lvl, hipStream_t st) {
@@ -722,12 +740,53 @@ void launch_conv(const ConvOp& op, hipStream_t st) {
   FFP_HIP(hipGetLastError());
 }
 
+int conv_tune(const ConvOp& op, hipStream_t st) {
+  const PackedConv& pc = *op.pc;
+  if (conv_direct_eligible(op)) return -1;
+  const ConvArgs a = make_conv_args(op);
+  if (conv_rows_eligible(op, a)) return -1;
+  const unsigned mask = pc.dt == F16 ? valid_t<_Float16>(a, pc.k, op.stride) : pc.split ? valid_t<X3>(a, pc.k, op.stride) : valid_t<float>(a, pc.k, op.stride);
+  if (__builtin_popcount(mask) < 2) return -1;
+  const int heur = pc.dt == F16 ? choose_t<_Float16>(a, pc.k, op.stride, op.out.lvl)
+                   : pc.split ? choose_t<X3>(a, pc.k, op.stride, op.out.lvl) : choose_t<float>(a, pc.k, op.stride, op.out.lvl);
+  hipEvent_t e0, e1;
+  FFP_HIP(hipEventCreate(&e0));
+  FFP_HIP(hipEventCreate(&e1));
+  auto time_shape = [&](int shape, int iters) {
+    ConvOp o = op;
+    o.force_shape = shape;
+    FFP_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) launch_conv(o, st);
+    FFP_HIP(hipEventRecord(e1, st));
+    FFP_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FFP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3f / iters;
+  };
+  float best_t = 0.f, heur_t = 0.f;
+  int best = -1;
+  for (int shape = 0; shape < 6; ++shape) {
+    if (!(mask & (1u << shape))) continue;
+    const float t1 = time_shape(shape, 2);                              // also builds the shape's tile table
+    const int iters = std::min(24, std::max(3, (int)(300.f / std::max(t1, 1.f))));
+    const float t = time_shape(shape, iters);
+    if (shape == heur) heur_t = t;
+    if (best < 0 || t < best_t) { best = shape; best_t = t; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  // keep the heuristic's choice unless another shape is clearly (> 3 %) faster: timing noise must not flip plans
+  if (heur_t > 0.f && best_t > 0.97f * heur_t) return heur;
+  return best;
+}
+
 std::string conv_variant(const ConvOp& op) {
   const PackedConv& pc = *op.pc;
   if (conv_direct_eligible(op)) return std::string(pc.dt == F32 ? "f32" : "f16") + "_k3_direct";
   const ConvArgs a = make_conv_args(op);
   if (conv_rows_eligible(op, a)) return "f16_k3s1_rows";
-  const int shape = pc.dt == F16 ? choose_t<_Float16>(a, pc.k, op.stride, op.out.lvl)
+  const int shape = (op.force_shape >= 0 && op.force_shape < 6) ? op.force_shape
+                    : pc.dt == F16 ? choose_t<_Float16>(a, pc.k, op.stride, op.out.lvl)
                     : pc.split ? choose_t<X3>(a, pc.k, op.stride, op.out.lvl) : choose_t<float>(a, pc.k, op.stride, op.out.lvl);
   char buf[64];
   snprintf(buf, sizeof(buf), "%s_k%ds%d_%s", pc.dt == F16 ? "f16" : pc.split ? "f32x3" : "f32", pc.k, op.stride, kShapeNames[shape < 0 ? 4 : shape]);

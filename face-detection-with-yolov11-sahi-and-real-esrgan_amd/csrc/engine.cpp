@@ -73,7 +73,9 @@ void Plan::add_conv(const ConvOp& op) {
   s.variant = conv_variant(o);
   s.name = op.pc->name;
   s.flops = o.flops;
-  s.run = [o](hipStream_t st) { launch_conv(o, st); };
+  s.conv = std::make_shared<ConvOp>(o);
+  std::shared_ptr<ConvOp> cp = s.conv;
+  s.run = [cp](hipStream_t st) { launch_conv(*cp, st); };
   conv_flops += o.flops;
   conv_launches += 1;
   steps.push_back(std::move(s));
@@ -109,7 +111,22 @@ static bool graphs_enabled() {
   return on;
 }
 
+void Plan::tune(hipStream_t st) {
+  tuned = true;
+  static const bool off = [] { const char* e = getenv("FFP_NO_TUNE"); return e && e[0] == '1'; }();
+  if (off) return;
+  for (Step& s : steps) {
+    if (!s.is_conv || s.conv->force_shape >= 0) continue;
+    const int best = conv_tune(*s.conv, st);
+    if (best >= 0) {
+      s.conv->force_shape = best;
+      s.variant = conv_variant(*s.conv);
+    }
+  }
+}
+
 void Plan::execute(hipStream_t st, ConvProfile* prof) {
+  if (!tuned) tune(st);
   const bool p = prof && prof->enabled;
   if (p) {                                   // per-launch events: always eager
     for (Step& s : steps) {

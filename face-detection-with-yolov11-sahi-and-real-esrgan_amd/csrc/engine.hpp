@@ -31,6 +31,7 @@ std::string conv_variant(const ConvOp& op);
 struct Step {
   std::function<void(hipStream_t)> run;
   bool is_conv = false;
+  std::shared_ptr<ConvOp> conv;      // is_conv: the descriptor `run` launches (its workgroup shape can be tuned after the plan is laid out)
   std::string variant, name;
   double flops = 0;
 };
@@ -56,6 +57,10 @@ struct Plan {
   void add_conv(const ConvOp& op);
   void add(std::function<void(hipStream_t)> f) { Step s; s.run = std::move(f); steps.push_back(std::move(s)); }
   void execute(hipStream_t st, ConvProfile* prof);
+  // time every valid workgroup shape of every dense conv on the plan's own buffers and keep the fastest (all shapes give
+  // bit-identical results: the accumulation order over k does not depend on the shape). FFP_NO_TUNE=1 keeps the heuristic.
+  void tune(hipStream_t st);
+  bool tuned = false;
 };
 
 // Process-wide gate between hipGraph capture and everything else the library does on other host threads: an allocation,

@@ -26,6 +26,9 @@ void launch_conv(const ConvOp& op, hipStream_t st);
 bool conv_direct_eligible(const ConvOp& op);
 void launch_conv_direct(const ConvOp& op, hipStream_t st);
 void conv_kernels_init();   // raise dynamic-LDS limits once per process
+// times the valid workgroup shapes of a generic-kernel conv on its own buffers; returns the fastest shape id, or -1 when
+// the op has a single candidate / goes to a specialised kernel (direct stem, row-reuse)
+int conv_tune(const ConvOp& op, hipStream_t st);
 
 // Depthwise 3x3, stride 1 (YOLO11 cls-tower DWConv and the PSA positional conv), fp32 math.
 // Input channel c is read from  in.coff + (c / grp) * grp_stride + grp_off + c % grp  (grp = C: identity) so that the
