@@ -70,3 +70,48 @@ def test_slice_grid_kats(gpu_lib):
     assert len(b) == 144 and b[:, 0].max() == 7040 and b[:, 1].max() == 3680
     assert len(gpu_lib.slice_bboxes(4320, 7680, 512, 512, 0.2, 0.2)) == 209
     assert gpu_lib.slice_bboxes(300, 400, 512, 512, 0.2, 0.2).tolist() == [[0, 0, 400, 300]]
+
+
+def test_two_host_threads_capture_gate(gpu_lib):
+    """A detector and an enhancer driven from two host threads: one thread's hipGraph capture (second run of a plan) must
+    survive the other thread's allocations / synchronisations (engine.cpp ApiShared / CaptureExclusive), and both
+    results must equal the single-threaded ones."""
+    import threading
+    from ffp_amd import synth
+    frame = synth.synthetic_frame(480, 640, seed=3)
+    det = gpu_lib.Detector(synth.yolo11_pose_weights("n"), arch="n", precision=gpu_lib.PREC_F32X3)
+    enh = gpu_lib.Enhancer(synth.rrdbnet_weights(4, 2), scale=4, num_block=2, half=True)
+    tiles = [(0, 0, 256, 256), (128, 64, 384, 320), (0, 0, 640, 480)]
+    crops = [frame[10:42, 20:60].copy(), frame[100:148, 200:248].copy()]
+    ref_d = det.infer_tiles(frame, tiles, 256, 0.05, 0.7, 300)
+    ref_s = enh.enhance_batch(crops)
+    out, err = {}, []
+
+    def run_det():
+        try:
+            for k in range(6):                      # new tile sets => new plans => eager run, then capture
+                t = tiles[:1 + k % 3]
+                out["d%d" % k] = det.infer_tiles(frame, t, 256, 0.05, 0.7, 300)
+                out["d%d" % k] = det.infer_tiles(frame, t, 256, 0.05, 0.7, 300)
+        except Exception as e:                      # pragma: no cover
+            err.append(e)
+
+    def run_sr():
+        try:
+            for k in range(6):
+                c = crops[:1 + k % 2]
+                out["s%d" % k] = enh.enhance_batch(c)
+                out["s%d" % k] = enh.enhance_batch(c)
+        except Exception as e:                      # pragma: no cover
+            err.append(e)
+
+    th = [threading.Thread(target=run_det), threading.Thread(target=run_sr)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    for a, b in zip(out["d2"], ref_d):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(out["s1"], ref_s):
+        np.testing.assert_array_equal(a, b)
