@@ -59,4 +59,22 @@ const int4* Level::tile_table(int th, int* n_tiles, hipStream_t st) {
   return it->second.first.as<int4>();
 }
 
+const int* Level::up2_map(const Level* src, hipStream_t st) {
+  auto it = up2_maps.find(src);
+  if (it == up2_maps.end()) {
+    FFP_CHECK(src->n == n, FFP_ERR_ARG, "up2_map: levels hold different batches");
+    std::vector<int> m((size_t)total_px);
+    for (int i = 0; i < n; ++i) {
+      FFP_CHECK(src->h[i] * 2 == h[i] && src->w[i] * 2 == w[i], FFP_ERR_ARG, "up2_map: image %d is %dx%d, source %dx%d", i, w[i], h[i], src->w[i], src->h[i]);
+      for (int y = 0; y < h[i]; ++y)
+        for (int x = 0; x < w[i]; ++x) m[(size_t)off[i] + (size_t)y * w[i] + x] = (int)(src->off[i] + (int64_t)(y >> 1) * src->w[i] + (x >> 1));
+    }
+    DevBuf b(sizeof(int) * m.size());
+    FFP_HIP(hipMemcpyAsync(b.p, m.data(), sizeof(int) * m.size(), hipMemcpyHostToDevice, st));
+    FFP_HIP(hipStreamSynchronize(st));
+    it = up2_maps.emplace(src, std::move(b)).first;
+  }
+  return it->second.as<int>();
+}
+
 }  // namespace ffp

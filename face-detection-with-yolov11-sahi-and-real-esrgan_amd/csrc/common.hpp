@@ -79,6 +79,9 @@ struct Level {
 
   void build(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st);
   const int4* tile_table(int th, int* n_tiles, hipStream_t st);
+  // for every pixel of this level the flat pixel index of its nearest-x2 source in `src` (same images at half size)
+  std::map<const Level*, DevBuf> up2_maps;
+  const int* up2_map(const Level* src, hipStream_t st);
   long long count_tiles(int th) const;
 };
 

@@ -25,6 +25,9 @@ struct ConvArgs {
   int act, out_f32, up, n_nblk, ncg, ntiles32, vec_ok, fast_out;
   int force_shape;   // tuning only: -1 auto
   int dbg;   // tuning only (ffp_op_conv2d_time): 1 skip stores, 2 skip MFMAs, 4 skip chunk refetch, 8 skip LDS stash
+  const void* up_src;  // 1x1 only: channels [0, up_c) come from this coarser view through up_map (see ConvOp::has_up2)
+  const int* up_map;
+  int up_c, up_cs;
   const void* zeros;   // 256 zero bytes in device memory (padding source of the LDS-DMA loader in conv_rows.hip)
 };
 

@@ -218,6 +218,18 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
       if (ok) isrc[i] = (unsigned)(rel * a.in_cs * ES);
     }
   }
+  // virtual concat [nearest_x2(coarser view) | rest] (1x1 only): for such a conv isrc[] carries the offsets into the coarser
+  // view (through the x2 pixel map) and the offsets into `in` are recomputed per load (one multiply), so that no shape
+  // pays registers for the second source
+  const unsigned char* upb = a.up_c > 0 ? reinterpret_cast<const unsigned char*>(a.up_src) : wb;
+  const auto rs_up = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<unsigned char*>(upb)), 0, 0x7FFFFFF0, 0x00020000);
+  if constexpr (KS == 1) {
+    if (a.up_c > 0) {
+#pragma unroll
+      for (int i = 0; i < RI; ++i)
+        if (isrc[i] != OOB) isrc[i] = (unsigned)a.up_map[in_base + (tid + i * 256) / VPP] * (unsigned)(a.up_cs * ES);
+    }
+  }
   unsigned wsrc[RW];           // byte offset of the fragment row start for k-group 0 (OOB: no such slot)
   int wkg[RW];
 #pragma unroll
@@ -236,10 +248,17 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
   constexpr int D = G::DEPTH;
   uint4 ri[D][RI], rw[D][RW];                      // D chunks in flight (static indexing: every loop over D is unrolled)
   auto fetch = [&](int c0, uint4 (&qi)[RI], uint4 (&qw)[RW]) {
+    const bool from_up = KS == 1 && c0 < a.up_c;          // chunk-uniform: up_c is a multiple of every chunk size
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
       const int c = c0 + ivec[i] * EPV;
-      qi[i] = bload(rs_in, (isrc[i] != OOB && c < a.cin) ? isrc[i] + (unsigned)(c * ES) : OOB);
+      if constexpr (KS == 1) {
+        unsigned so = isrc[i];
+        if (a.up_c > 0 && !from_up && so != OOB) so = (unsigned)(((tid + i * 256) / VPP) * a.in_cs * ES);
+        qi[i] = bload(from_up ? rs_up : rs_in, (so != OOB && c < a.cin) ? so + (unsigned)(c * ES) : OOB);
+      } else {
+        qi[i] = bload(rs_in, (isrc[i] != OOB && c < a.cin) ? isrc[i] + (unsigned)(c * ES) : OOB);
+      }
     }
     const int cg0 = c0 / KG;
 #pragma unroll
@@ -721,6 +740,16 @@ ConvArgs make_conv_args(const ConvOp& op) {
     if (op.has_res1) f = f && op.res1.cs % cpl == 0 && op.res1.coff % cpl == 0;
     if (op.has_res2) f = f && op.res2.cs % cpl == 0 && op.res2.coff % cpl == 0;
     a.fast_out = f ? 1 : 0;
+  }
+  a.up_src = nullptr; a.up_map = nullptr; a.up_c = 0; a.up_cs = 0;
+  if (op.has_up2) {
+    FFP_CHECK(pc.k == 1 && op.stride == 1 && op.up2.dt == pc.dt && op.up2_c > 0 && op.up2_c % 64 == 0 && op.up2_c <= pc.cin && op.up2.C == op.up2_c,
+              FFP_ERR_ARG, "conv %s: x2-source needs a 1x1 conv and a channel count that is a multiple of 64", pc.name.c_str());
+    FFP_CHECK(op.up2.cs % epv == 0 && op.up2.coff % epv == 0, FFP_ERR_ARG, "conv %s: x2-source view not 16-byte aligned", pc.name.c_str());
+    a.up_src = reinterpret_cast<const unsigned char*>(op.up2.ptr) + (size_t)op.up2.coff * dsize(pc.dt);
+    a.up_map = op.up2_map;
+    a.up_c = op.up2_c; a.up_cs = op.up2.cs;
+    FFP_CHECK(a.up_map != nullptr, FFP_ERR_STATE, "conv %s: x2-source map missing", pc.name.c_str());
   }
   a.dbg = op.dbg;
   a.force_shape = op.force_shape;

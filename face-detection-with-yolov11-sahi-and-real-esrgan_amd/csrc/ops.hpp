@@ -17,6 +17,13 @@ struct ConvOp {
   bool has_res1 = false, has_res2 = false;
   TView res1, res2;
   float s1 = 1.f, s2 = 1.f;
+  // 1x1 convs over a virtual concat [nearest_x2(up2) | rest]: input channels [0, up2_c) are read from `up2` (a view one
+  // level coarser) through the level's x2 pixel map instead of from `in` (YOLO neck: Upsample + Concat + C3k2.cv1 without
+  // materialising the upsampled tensor)
+  bool has_up2 = false;
+  TView up2;
+  int up2_c = 0;
+  const int* up2_map = nullptr;   // device: Level::up2_map of in.lvl over up2.lvl
   double flops = 0;   // 2*MAC, algorithmic (unpadded)
   int dbg = 0;        // tuning only: phase-skip mask (see ConvArgs::dbg)
   int force_shape = -1;   // tuning only: 0 wide .. 5 narrow1H

@@ -86,10 +86,12 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
   const int c64 = ch(64), c128 = ch(128), c256 = ch(256), c512 = ch(512), c1024 = ch(1024);
   const DType T = dt_;
 
-  auto cv = [&](const std::string& name, const TView& in, const TView& out, int stride, int act, const TView* res = nullptr) {
+  static const bool fold_up = !getenv("FFP_NO_UPFOLD");
+  auto cv = [&](const std::string& name, const TView& in, const TView& out, int stride, int act, const TView* res = nullptr, const TView* up2 = nullptr) {
     ConvOp o;
     o.pc = conv(name); o.in = in; o.out = out; o.stride = stride; o.act = act;
     if (res) { o.has_res1 = true; o.res1 = *res; o.s1 = 1.f; }
+    if (up2) { o.has_up2 = true; o.up2 = *up2; o.up2_c = up2->C; o.up2_map = in.lvl->up2_map(up2->lvl, st_); }
     FFP_CHECK(o.pc->cin == in.C && o.pc->cout == out.C, FFP_ERR_WEIGHTS, "%s: weights are %d->%d, graph expects %d->%d",
               name.c_str(), o.pc->cin, o.pc->cout, in.C, out.C);
     P.add_conv(o);
@@ -106,10 +108,10 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
     cv(p + ".cv2.conv", t, out, 1, ACT_SILU, &x);
   };
   // C3k2(c1, c2, n=1, c3k, e): cat = [a | b | m(b)]; out = cv2(cat)
-  auto c3k2 = [&](const std::string& p, const TView& in, const TView& out, int c2, bool c3k, double e) {
+  auto c3k2 = [&](const std::string& p, const TView& in, const TView& out, int c2, bool c3k, double e, const TView* up2 = nullptr) {
     const int c = (int)(c2 * e);
     TView cat = P.alloc(in.lvl, 3 * c, T);
-    cv(p + ".cv1.conv", in, cat.slice(0, 2 * c), 1, ACT_SILU);
+    cv(p + ".cv1.conv", in, cat.slice(0, 2 * c), 1, ACT_SILU, nullptr, up2);
     const TView b = cat.slice(c, c), mo = cat.slice(2 * c, c);
     if (!c3k) {
       bottleneck(p + ".m.0", b, mo, c / 2);
@@ -202,17 +204,19 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
     cv("model.10.cv2.conv", pb, x10, 1, ACT_SILU);
   }
   // ---- neck ------------------------------------------------------------------------------------------------------------
-  {
+  // Upsample + Concat feed a 1x1 conv only: its loader reads the coarse tensor through the x2 pixel map (no upsampled copy)
+  const bool fold12 = fold_up && c1024 % 64 == 0, fold15 = fold_up && c512 % 64 == 0;
+  if (!fold12) {
     const TView up = cat12.slice(0, c1024);
     P.add([x10, up](hipStream_t s) { launch_upsample2x(x10, up, s); });
   }
-  c3k2("model.13", cat12, x13, c512, false, 0.5);
-  {
+  c3k2("model.13", cat12, x13, c512, false, 0.5, fold12 ? &x10 : nullptr);
+  if (!fold15) {
     const TView up = cat15.slice(0, c512);
     P.add([x13, up](hipStream_t s) { launch_upsample2x(x13, up, s); });
   }
   TView x16 = P.alloc(P.L[3], c256, T);
-  c3k2("model.16", cat15, x16, c256, false, 0.5);
+  c3k2("model.16", cat15, x16, c256, false, 0.5, fold15 ? &x13 : nullptr);
   cv("model.17.conv", x16, cat18.slice(0, c256), 2, ACT_SILU);
   TView x19 = P.alloc(P.L[4], c512, T);
   c3k2("model.19", cat18, x19, c512, false, 0.5);
