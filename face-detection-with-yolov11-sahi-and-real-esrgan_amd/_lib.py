@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -71,6 +72,7 @@ _SIGS = {
     "ffp_sr_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_void_p)]),
     "ffp_sr_destroy": (None, [C.c_void_p]),
     "ffp_sr_enhance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ffp_sr_enhance_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ffp_sr_enhance_batch": (C.c_int, [C.c_void_p, C.c_int, _p(C.c_void_p), _p(C.c_int32), _p(C.c_int32), C.c_int, C.c_int, C.c_int,
                                        _p(C.c_void_p)]),
     "ffp_sr_enhance_crops_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _p(C.c_int32), C.c_int, C.c_void_p, C.c_size_t,
@@ -101,6 +103,16 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m ffp_amd.build` "
                                "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.")
+        # A process that also uses torch's device runtime must bring that one up FIRST: PyTorch-ROCm wheels carry their own
+        # copy of the HIP runtime, and once libffp.so has initialised the system copy torch reports "No HIP GPUs are available"
+        # (the other order works; observed on ROCm 7.2 + torch 2.10/rocm7.0).
+        if "torch" in sys.modules:
+            try:
+                t = sys.modules["torch"]
+                if t.cuda.is_available() and not t.cuda.is_initialized():
+                    t.cuda.init()
+            except Exception:
+                pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             f = getattr(l, name)

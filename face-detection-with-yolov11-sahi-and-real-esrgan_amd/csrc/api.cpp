@@ -381,6 +381,17 @@ static int sr_crops_impl(ffp_sr* s, int n_frames, const uint8_t* const* d_frames
   FFP_API_END
 }
 
+int ffp_sr_enhance_dev(ffp_sr* s, const uint8_t* d_bgr, int h, int w, int tile, int tile_pad, int pre_pad, uint8_t* d_out) {
+  FFP_API_BEGIN
+  FFP_CHECK(s && d_bgr && d_out, FFP_ERR_ARG, "null argument");
+  FFP_CHECK(h >= 1 && w >= 1, FFP_ERR_ARG, "empty image");
+  SrImage im;
+  im.in_off = 0; im.in_stride = w * 3; im.h = h; im.w = w;
+  im.out_off = 0; im.out_stride = w * s->eng.scale() * 3;
+  s->eng.enhance_dev(d_bgr, d_out, {im}, tile, tile_pad, pre_pad);
+  FFP_API_END
+}
+
 int ffp_sr_enhance_crops_dev(ffp_sr* s, const uint8_t* d_frame, int H, int W, const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap,
                              int64_t* out_offsets) {
   return sr_crops_impl(s, 1, &d_frame, nullptr, H, W, boxes, n, d_out, out_cap, out_offsets, true);

@@ -190,5 +190,25 @@ class FramePipeline:
                                                                     out.data_ptr(), tot, offs.ctypes.data_as(C.POINTER(C.c_int64))))
         return out, offs
 
+    def enhance_frame(self, d_frame_bgr, H: int, W: int, enhancer=None, tile: int = 400, tile_pad: int = 10, pre_pad: int = 0):
+        """RealESRGANer.enhance of a whole resident BGR frame (tiled like FaceEnhancer does, utils/enhancer.py:138-156) ->
+        resident BGR frame (scale*H, scale*W, 3). `enhancer`: an `_lib.Enhancer` (e.g. the x2plus model) or the pipeline's own."""
+        sr = enhancer if enhancer is not None else self.sr
+        s = sr.scale
+        out = self._buf(f"sr_frame{s}", (H * s, W * s, 3), self.torch.uint8)
+        _lib._check(_lib.lib().ffp_sr_enhance_dev(sr.handle, d_frame_bgr.data_ptr(), H, W, tile, tile_pad, pre_pad, out.data_ptr()))
+        return out
+
+    def enhance_first(self, d_frame_bgr, H: int, W: int, enhancer=None, tile: int = 400, tile_pad: int = 10):
+        """The reference's enhance-first ordering (pipeline_v4_yolo/app_yolo_full.py:87-123): super-resolve the whole picture,
+        then sliced detection + merge on the enhanced picture (boxes are in enhanced coordinates, as the reference draws them;
+        eval/eval_dual.py:262-265 divides by the scale). Needs cfg.chan_order == CHAN_AS_BGR (the enhancer's output order).
+        Returns (enhanced frame, merged rows, count) — all resident."""
+        enh = self.enhance_frame(d_frame_bgr, H, W, enhancer, tile, tile_pad)
+        He, We = int(enh.shape[0]), int(enh.shape[1])
+        dets, counts, items = self.detect(enh, He, We, 1)
+        rows, n = self.merge_frame(dets, counts, 0, items.shape[0])
+        return enh, rows, n
+
     def wait_sr(self):
         _lib._check(_lib.lib().ffp_sr_wait(self.sr.handle))

@@ -165,6 +165,11 @@ void ffp_sr_destroy(ffp_sr* s);
 int ffp_sr_enhance(ffp_sr* s, const uint8_t* bgr_hwc, int h, int w, int tile, int tile_pad, int pre_pad,
                    uint8_t* out_bgr);
 
+/* The same for an image resident in device memory, output written to device memory ((scale*h) x (scale*w) x 3, tightly
+ * packed): the enhance-first ordering (pipeline_v4_yolo/app_yolo_full.py:87-123 — FaceEnhancer.enhance_image on the
+ * whole picture, utils/enhancer.py:189-235, then get_sliced_prediction on the result) without a host round trip. */
+int ffp_sr_enhance_dev(ffp_sr* s, const uint8_t* d_bgr_hwc, int h, int w, int tile, int tile_pad, int pre_pad, uint8_t* d_out_bgr);
+
 /* n independent images in one ragged batch (one launch per layer for all of them). */
 int ffp_sr_enhance_batch(ffp_sr* s, int n, const uint8_t* const* imgs, const int32_t* hs, const int32_t* ws, int tile,
                          int tile_pad, int pre_pad, uint8_t* const* outs);

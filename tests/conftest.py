@@ -22,6 +22,9 @@ def ffp():
 def gpu_lib(ffp):
     """The loaded HIP library on a machine with a GPU. Fails (not skips) when the library is missing: GPU tests
     must exercise the native path."""
+    # torch carries its own copy of the HIP runtime and must be brought up before libffp.so initialises the system copy
+    # (ffp_amd._lib.lib() does this by itself when torch is already imported)
+    import torch  # noqa: F401
     from ffp_amd import _lib
     l = _lib.lib()
     assert _lib.device_count() > 0, "no HIP device visible"
