@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--det-precision", default="f32x3", choices=["f32", "f32x3", "f16"],
                     help="f32: exact-fp32 MFMA; f32x3: fp32 storage, fp16 hi/lo split products (fp32-grade); f16: speed mode")
     ap.add_argument("--sr-crops", type=int, default=32, help="crops enhanced per frame (0: config 2, detection only)")
-    ap.add_argument("--pp-type", default="GREEDYNMM")
+    ap.add_argument("--pp-type", default="GREEDYNMM", choices=["GREEDYNMM", "NMS"])
+    ap.add_argument("--class-agnostic", action="store_true", help="merge across classes (the reference's eval setting with NMS)")
     ap.add_argument("--conf", type=float, default=0.5)
     ap.add_argument("--distinct-frames", type=int, default=2)
     ap.add_argument("--sr-batch-frames", type=int, default=2,
@@ -121,7 +122,7 @@ def main():
 
     H, W, B = args.height, args.width, world
     cfg = pipeline.PipeConfig(slice_h=args.slice, slice_w=args.slice, overlap=args.overlap, imgsz=args.imgsz, conf=args.conf,
-                              pp_type=args.pp_type, sr_crops=args.sr_crops)
+                              pp_type=args.pp_type, class_agnostic=args.class_agnostic, sr_crops=args.sr_crops)
     det_w = synth.yolo11_pose_weights(args.arch)
     sr_w = synth.rrdbnet_weights(4, 23) if args.sr_crops > 0 else None
     pipe = pipeline.FramePipeline(det_w, sr_w, cfg, arch=args.arch, device=local_rank,
@@ -271,7 +272,7 @@ def main():
             "dtype": f"{args.det_precision}(detect)+f16(sr)" if args.sr_crops > 0 else args.det_precision, "data": "synthetic",
             "config": {"workload": f"{W}x{H} frame, YOLO11{args.arch}-pose (random-init), SAHI {args.slice}x{args.slice}/{args.overlap} "
                                    f"({items_per_frame - 1} slices + full frame), net input {args.imgsz}, conf {args.conf}, NMS 0.7, "
-                                   f"{args.pp_type}/IOS/0.5 merge" + (f", Real-ESRGAN x4 on {args.sr_crops} crops/frame "
+                                   f"{args.pp_type}/IOS/0.5{'/agnostic' if args.class_agnostic else ''} merge" + (f", Real-ESRGAN x4 on {args.sr_crops} crops/frame "
                                    f"({int((sizes[:args.sr_crops] ** 2).sum())} px)" if args.sr_crops > 0 else ", no SR"),
                        "frames_per_step": B, "det_batch_frames": DB, "sr_batch_frames": args.sr_batch_frames, "parallelism": f"items sharded over {world} rank(s), 1 all-gather" if world > 1 else "single GPU",
                        "detections_last_frame": int(state.get("rows", np.zeros((0, 1))).shape[0])},
