@@ -58,6 +58,8 @@ CASES = [
     (1, 96, 96, 192, 64, 3, 1, 0, 0, True),
     (2, 17, 16, 64, 64, 3, 1, 2, 1, False),
     (1, 1, 1, 64, 32, 3, 1, 2, 0, False),
+    (1, 20, 20, 64, 128, 3, 1, 1, 0, False),    # row-reuse kernel with 4 / 3 channel blocks per pixel tile
+    (1, 16, 24, 128, 96, 3, 1, 0, 0, True),
 ]
 
 
