@@ -360,6 +360,90 @@ __global__ void __launch_bounds__(256) psa_attention_kernel(const T* __restrict_
   for (int d = 0; d < HD; ++d) stf(op + d, o[d] * inv);
 }
 
+// The same attention on the matrix cores (exact-fp32 MFMA 32x32x2): a wave owns 32 queries (one per lane column), a
+// workgroup 128. Per block of 32 keys: S[key][query] = K Q^T (16 MFMAs, A = K rows from LDS, B = the lane's own query,
+// pre-scaled), online softmax per query (a lane holds 16 of its query's 32 scores, the other 16 sit in lane ^ 32), then
+// O[dim][query] += V^T P (2 x 16 MFMAs): the k-order of that product is chosen so that the B operand of step t is exactly
+// the lane's score register t — no data movement between the two products.
+template <typename T>
+__global__ void __launch_bounds__(256) psa_attention_mfma_kernel(const T* __restrict__ qkv, int q_cs, int q_coff, T* __restrict__ out, int o_cs,
+                                                                 int o_coff, const int4* __restrict__ tab, float scale) {
+  constexpr int KD = 32, HD = 64, KB = 64;
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  __shared__ float ks[KB][KD + 1];          // +1: the 32 lanes of an A-operand read walk 32 different keys at one d
+  __shared__ float vs[KB][HD + 4];
+  const int4 t = tab[blockIdx.z];
+  const int N = t.y * t.z;
+  if (blockIdx.x * 128 >= N) return;
+  const int head = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, hh = lane >> 5;
+  const int hoff = q_coff + head * (2 * KD + HD);
+  const int qi = blockIdx.x * 128 + wave * 32 + n;
+  const bool active = qi < N;
+  float qreg[16];
+  {
+    const T* qp = qkv + ((size_t)t.x + (active ? qi : N - 1)) * q_cs + hoff;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) qreg[s] = ldf(qp + 2 * s + hh) * scale;
+  }
+  float m = -INFINITY, l = 0.f;
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  for (int j0 = 0; j0 < N; j0 += KB) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < KB * ((KD + HD) / 4); i += 256) {       // 24 float4 per key: [k(32) | v(64)]
+      const int j = i / ((KD + HD) / 4), d = (i - j * ((KD + HD) / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j0 + j < N) v = ld4<T>(qkv + ((size_t)t.x + j0 + j) * q_cs + hoff + KD + d);
+      float* dst = d < KD ? &ks[j][d] : &vs[j][d - KD];
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kb = 0; kb < KB && j0 + kb < N; kb += 32) {
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[kb + n][2 * s + hh], qreg[s], sc, 0, 0, 0);
+      // register r = 4g + j holds key kb + 8g + 4hh + j of this lane's query
+      float bm = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = j0 + kb + 8 * (r >> 2) + 4 * hh + (r & 3);
+        if (key >= N) sc[r] = -INFINITY;
+        bm = fmaxf(bm, sc[r]);
+      }
+      bm = fmaxf(bm, __shfl_xor(bm, 32));
+      const float mn = fmaxf(m, bm);
+      const float f = expf(m - mn);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = expf(sc[r] - mn); ps += sc[r]; }
+      ps += __shfl_xor(ps, 32);
+      l = l * f + ps;
+      m = mn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= f; o1[r] *= f; }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int key = kb + 8 * (s >> 2) + 4 * hh + (s & 3);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[key][n], sc[s], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[key][32 + n], sc[s], o1, 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+  const float inv = 1.0f / l;
+  T* op = out + ((size_t)t.x + qi) * o_cs + o_coff + head * HD;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    st4<T>(op + 8 * g + 4 * hh, make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+    st4<T>(op + 32 + 8 * g + 4 * hh, make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+  }
+}
+
 // ---- LetterBox + normalise ------------------------------------------------------------------------------------------
 // cv2.resize INTER_LINEAR for uint8 restated in fixed point (11-bit coefficients, two-pass rounding), pad value 114,
 // /255, optional channel flip, NHWC with CPAD channels (>= 3, rest zero).
@@ -599,8 +683,20 @@ void launch_psa_attention(const TView& qkv, const TView& out, int nh, int kd, in
   FFP_CHECK(qkv.C == nh * (2 * kd + hd) && out.C == nh * hd && qkv.lvl == out.lvl, FFP_ERR_ARG, "psa attention: view mismatch");
   int nmax = 0;
   for (int i = 0; i < qkv.lvl->n; ++i) nmax = std::max(nmax, qkv.lvl->h[i] * qkv.lvl->w[i]);
-  dim3 grid((nmax + 255) / 256, nh, qkv.lvl->n);
   const float scale = 1.0f / sqrtf((float)kd);
+  static const bool valu = [] { const char* e = getenv("FFP_ATTN_VALU"); return e && e[0] == '1'; }();
+  if (!valu && qkv.cs % 4 == 0 && qkv.coff % 4 == 0 && out.cs % 4 == 0 && out.coff % 4 == 0) {
+    dim3 g2((nmax + 127) / 128, nh, qkv.lvl->n);
+    if (qkv.dt == F32)
+      hipLaunchKernelGGL((psa_attention_mfma_kernel<float>), g2, dim3(256), 0, st, (const float*)qkv.ptr, qkv.cs, qkv.coff, (float*)out.ptr, out.cs,
+                         out.coff, qkv.lvl->d_tab.as<int4>(), scale);
+    else
+      hipLaunchKernelGGL((psa_attention_mfma_kernel<_Float16>), g2, dim3(256), 0, st, (const _Float16*)qkv.ptr, qkv.cs, qkv.coff, (_Float16*)out.ptr,
+                         out.cs, out.coff, qkv.lvl->d_tab.as<int4>(), scale);
+    FFP_HIP(hipGetLastError());
+    return;
+  }
+  dim3 grid((nmax + 255) / 256, nh, qkv.lvl->n);
   if (qkv.dt == F32)
     hipLaunchKernelGGL((psa_attention_kernel<float, 32, 64>), grid, dim3(256), 0, st, (const float*)qkv.ptr, qkv.cs, qkv.coff,
                        (float*)out.ptr, out.cs, out.coff, qkv.lvl->d_tab.as<int4>(), scale);
