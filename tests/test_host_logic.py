@@ -110,3 +110,20 @@ def test_frame_items_and_sharding(lib):
     assert set(sizes.tolist()) <= {24, 32, 48, 64, 96}
     b = pipeline.crop_boxes_for_sr(np.zeros((0, 21), np.float32), 2160, 3840, 32, sizes, seed=3)
     assert ((b[:, 2] - b[:, 0]) == sizes).all() and (b[:, 0] >= 0).all() and (b[:, 2] <= 3840).all() and (b[:, 3] <= 2160).all()
+
+
+def test_pmc_symbol_to_variant_mapping():
+    """tools/pmc_traffic.py keys the PMC table by the variant names bench.py reports (roofline.traffic lookup)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("pmc_traffic", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pmc_traffic.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    v = m.variant
+    assert v("void ffp::(anonymous namespace)::conv_rows_kernel<1, 2>(ffp::ConvArgs)") == "f16_k3s1_rows"
+    assert v("void ffp::conv_mfma_kernel<ffp::X3, 1, 1, 2, 2, 4, 2, 16>(ffp::ConvArgs)") == "f32x3_k1s1_wide"
+    assert v("void ffp::conv_mfma_kernel<ffp::X3, 3, 2, 4, 1, 1, 2, 16>(ffp::ConvArgs)") == "f32x3_k3s2_narrow2"
+    assert v("void ffp::conv_mfma_kernel<ffp::X3, 3, 1, 4, 1, 1, 1, 16>(ffp::ConvArgs)") == "f32x3_k3s1_narrow1H"
+    assert v("_ZN3ffp16conv_mfma_kernelIDF16_Li3ELi1ELi4ELi1ELi2ELi1ELi16EEEvNS_8ConvArgsE") == "f16_k3s1_narrow1"
+    assert v("void ffp::conv_mfma_kernel<float, 1, 1, 2, 2, 2, 2, 32>(ffp::ConvArgs)") == "f32_k1s1_wideH"
+    assert v("__amd_rocclr_copyBuffer") is None
