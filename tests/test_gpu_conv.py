@@ -122,3 +122,27 @@ def test_conv_depthwise(gpu_lib, c, h, w, act, has_res, half):
         r = r + (rr.half().float() if half else rr)
     ref = r.permute(0, 2, 3, 1).numpy()
     np.testing.assert_allclose(y, ref, rtol=2e-3 if half else 2e-5, atol=2e-3 if half else 2e-5)
+
+
+def test_conv_rows_kernel_random_shapes(gpu_lib):
+    """Seeded sweep of the row-reuse fp16 3x3 kernel (conv_rows.hip) over ragged sizes, channel blocks, activations, the
+    folded x2 upsample and the residual epilogue; every case is also run through the generic kernel (force via cin % 32 != 0
+    is impossible here, so the comparison is against the PyTorch reference only)."""
+    rng = np.random.default_rng(20260101)
+    for it in range(24):
+        n = int(rng.integers(1, 4))
+        h, w = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+        cin = int(rng.choice([64, 96, 128, 160, 192]))
+        cout = int(rng.choice([32, 64, 96, 128]))
+        act = int(rng.choice([0, 1, 2]))
+        up = int(rng.integers(0, 2)) if h * w <= 900 else 0
+        has_res = bool(rng.integers(0, 2))
+        x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+        wt = (rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) / np.sqrt(cin * 9)).astype(np.float32)
+        b = rng.standard_normal(cout, dtype=np.float32) * 0.1
+        ho, wo = (h * 2, w * 2) if up else (h, w)
+        res = rng.standard_normal((n, ho, wo, cout), dtype=np.float32) if has_res else None
+        y = gpu_lib.op_conv2d(x, wt, b, stride=1, act=act, up=bool(up), res=res, res_scale=0.2 if has_res else 1.0, precision=gpu_lib.PREC_F16)
+        ref = ref_conv(x, wt, b, 1, 1, act, up, res, 0.2, True)
+        assert y.shape == ref.shape, (it, y.shape, ref.shape)
+        np.testing.assert_allclose(y, ref, rtol=2e-3, atol=2e-3, err_msg=f"case {it}: n{n} {h}x{w} {cin}->{cout} act{act} up{up} res{has_res}")
