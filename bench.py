@@ -4,11 +4,15 @@
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch of synthetic 4K frames resident in HBM (batch = n_gpus frames, one
-frame at N=1): SAHI 512x512 / 0.2 slicing (60 slices + the full-frame pass), YOLO11s-pose on every item at net input
-512, per-item NMS, int-truncate + shift, [N>1: RCCL all-gather of the fixed-cap boxes], SAHI GREEDYNMM/IOS/0.5 merge,
-merged detections to host, Real-ESRGAN x4 on 32 crops per frame, enhanced crops to host.
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and, at N=1, `cpu_baseline`.
+A step = one pass of the hot path over one batch of synthetic 4K frames (batch = n_gpus frames, one frame at N=1), timed
+over the span SURVEY.md §8(d) defines — from the decoded uint8 frame in (pinned) HOST memory to merged detections and
+enhanced crops back in host memory: frame upload (copy stream, overlapped with the previous group's kernels), SAHI
+512x512 / 0.2 slicing (60 slices + the full-frame pass), YOLO11s-pose on every item at net input 512, per-item NMS,
+int-truncate + shift, [RCCL all-gather of the fixed-cap boxes when a frame's items are spread over ranks], SAHI
+GREEDYNMM/IOS/0.5 merge, merged detections to host, Real-ESRGAN x4 on 32 crops per frame whose sizes change every frame,
+enhanced crops to host. Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`, `secondary`
+(the reference-default image_size=1024, the eval merge NMS/IOS/agnostic, the exact-fp32 detector, fixed crop sizes, frames
+already resident in HBM; at N>1 the forced all-gather and ONE frame's slices across the ranks) and, at N=1, `cpu_baseline`.
 """
 from __future__ import annotations
 
@@ -39,36 +43,48 @@ def parse():
     ap.add_argument("--imgsz", type=int, default=512, help="network input size (512 = native tile; 1024 = reference wrapper default)")
     ap.add_argument("--arch", default="s")
     ap.add_argument("--det-precision", default="f32x3", choices=["f32", "f32x3", "f16"],
-                    help="f32: exact-fp32 MFMA; f32x3: fp32 storage, fp16 hi/lo split products (fp32-grade); f16: speed mode")
+                    help="f32: exact-fp32 MFMA; f32x3: fp32 storage, scaled fp16 hi/lo split products (fp32-grade); f16: speed mode")
     ap.add_argument("--sr-crops", type=int, default=32, help="crops enhanced per frame (0: config 2, detection only)")
+    ap.add_argument("--sr-sizes", default="random-per-frame", choices=["random-per-frame", "fixed", "from-detections"],
+                    help="crop sizes: SURVEY §8(d) law re-drawn for every frame (what a real stream looks like to the enhancer), "
+                         "the same multiset every frame, or the merged boxes themselves")
     ap.add_argument("--pp-type", default="GREEDYNMM", choices=["GREEDYNMM", "NMS"])
     ap.add_argument("--class-agnostic", action="store_true", help="merge across classes (the reference's eval setting with NMS)")
     ap.add_argument("--conf", type=float, default=0.5)
     ap.add_argument("--distinct-frames", type=int, default=2)
+    ap.add_argument("--frames-per-step", type=int, default=0, help="frames per step over ALL ranks (0: one per rank = weak scaling; "
+                                                                    "1 with --gpus N: ONE frame's slices across the ranks = strong scaling)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "always", "never"],
+                    help="all-gather of the per-item detections: auto = only when a frame's items are spread over ranks")
+    ap.add_argument("--resident", action="store_true", help="frames already in HBM when the timed region starts (no upload in the span)")
     ap.add_argument("--sr-batch-frames", type=int, default=2,
                     help="frames whose crops are enhanced together as one ragged Real-ESRGAN batch (1: per frame)")
     ap.add_argument("--det-batch-frames", type=int, default=2,
                     help="consecutive steps whose frames are detected together as one ragged batch of slices (1: per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", action="store_true", help="CPU baseline on a bounded sample (3 slices + 3 crops) instead of one whole frame")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--secondary-steps", type=int, default=8)
     return ap.parse_args()
 
 
 def cpu_baseline(args, det_w, sr_w, frame, crop_boxes, premerge_rows):
-    """The oracle (CPU restatement, torch fp32) timed on a bounded sample of the same workload and scaled to one frame."""
+    """The oracle (CPU restatement, torch fp32) timed on the GPU box's host cores over ONE WHOLE FRAME of the same workload, in the
+    reference's own order: one slice at a time (docs sahi/predict.py:270-298), the full-frame pass, the merge, one crop at a time
+    (utils/enhancer.py:344-391). --cpu-sample times 3 slices + the full-frame pass + 3 crops and scales."""
     import torch
     from oracle import rrdbnet_ref, sahi_ref, ultra_post
     from oracle.yolo11_ref import Yolo11PoseRef
     H, W = frame.shape[:2]
     ref = Yolo11PoseRef(det_w, args.arch)
     boxes = sahi_ref.get_slice_bboxes(H, W, args.slice, args.slice, args.overlap, args.overlap)
-    n_sample = 3
-    idx = np.linspace(0, len(boxes) - 1, n_sample).astype(int)
+    idx = np.linspace(0, len(boxes) - 1, 3).astype(int) if args.cpu_sample else np.arange(len(boxes))
     ultra_post.predict(ref, frame[:args.slice, :args.slice], args.imgsz, args.conf)   # warm-up (scripts/inference_time.py:46-52)
     t0 = time.perf_counter()
     for i in idx:
         x0, y0, x1, y1 = boxes[i]
         ultra_post.predict(ref, frame[y0:y1, x0:x1], args.imgsz, args.conf)
-    t_slice = (time.perf_counter() - t0) / n_sample
+    t_slices = (time.perf_counter() - t0) / len(idx) * len(boxes)
     t0 = time.perf_counter()
     ultra_post.predict(ref, frame, args.imgsz, args.conf)
     t_full = time.perf_counter() - t0
@@ -78,9 +94,9 @@ def cpu_baseline(args, det_w, sr_w, frame, crop_boxes, premerge_rows):
         sahi_ref.postprocess(dets, args.pp_type, "IOS", 0.5, False)
     t_merge = time.perf_counter() - t0
     t_sr_frame, sr_sample = 0.0, "none"
-    if args.sr_crops > 0:
+    if args.sr_crops > 0 and len(crop_boxes):
         net = rrdbnet_ref.RRDBNetRef(sr_w, 4, 23)
-        sample = [b for b in crop_boxes if (b[2] - b[0]) <= 48][:3] or [crop_boxes[0]]
+        sample = ([b for b in crop_boxes if (b[2] - b[0]) <= 48][:3] or [crop_boxes[0]]) if args.cpu_sample else list(crop_boxes)
         px = 0
         t0 = time.perf_counter()
         for b in sample:
@@ -89,11 +105,221 @@ def cpu_baseline(args, det_w, sr_w, frame, crop_boxes, premerge_rows):
         t_sr = time.perf_counter() - t0
         tot_px = sum(int(b[2] - b[0]) * int(b[3] - b[1]) for b in crop_boxes)
         t_sr_frame = t_sr / px * tot_px
-        sr_sample = f"{len(sample)} crops ({px} px of {tot_px})"
-    t_frame = t_slice * len(boxes) + t_full + t_merge + t_sr_frame
+        sr_sample = f"{len(sample)} of {len(crop_boxes)} crops ({px} px of {tot_px})"
+    t_frame = t_slices + t_full + t_merge + t_sr_frame
+    what = "bounded sample scaled to one frame" if args.cpu_sample else "one whole frame"
     return {"value": 1.0 / t_frame, "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"{n_sample} of {len(boxes)} slices + full-frame pass + merge of {len(dets)} boxes + SR on {sr_sample}, "
-                      f"scaled to one frame ({t_frame:.1f} s/frame: det {t_slice * len(boxes) + t_full:.1f}, merge {t_merge:.3f}, sr {t_sr_frame:.1f})"}
+            "sample": f"{what}: {len(idx)} of {len(boxes)} slices + full-frame pass + merge of {len(dets)} boxes + SR on {sr_sample} "
+                      f"({t_frame:.1f} s/frame: det {t_slices + t_full:.1f}, merge {t_merge:.3f}, sr {t_sr_frame:.1f})"}
+
+
+class Runner:
+    """One configuration of the hot path: its pipeline, its resident plans, its timed loop."""
+
+    def __init__(self, args, ctx, *, det_precision=None, imgsz=None, pp_type=None, class_agnostic=None, sr_sizes=None, frames_per_step=None,
+                 exchange=None, resident=None, pipe=None):
+        import torch
+        from ffp_amd import _lib, pipeline, synth
+        self.torch, self.pipeline, self.ctx, self.args = torch, pipeline, ctx, args
+        self.rank, self.world, self.dev = ctx["rank"], ctx["world"], ctx["dev"]
+        self.det_precision = det_precision or args.det_precision
+        self.imgsz = imgsz or args.imgsz
+        self.pp_type = pp_type or args.pp_type
+        self.class_agnostic = args.class_agnostic if class_agnostic is None else class_agnostic
+        self.sr_sizes = sr_sizes or args.sr_sizes
+        self.B = frames_per_step or args.frames_per_step or self.world
+        self.exchange = exchange or args.exchange
+        self.resident = args.resident if resident is None else resident
+        self.H, self.W = args.height, args.width
+        self.DB = max(1, args.det_batch_frames)
+        self.SB = max(1, args.sr_batch_frames)
+        self.cfg = pipeline.PipeConfig(slice_h=args.slice, slice_w=args.slice, overlap=args.overlap, imgsz=self.imgsz, conf=args.conf,
+                                       pp_type=self.pp_type, class_agnostic=self.class_agnostic, sr_crops=args.sr_crops)
+        if pipe is not None and pipe.det.precision == {"f16": _lib.PREC_F16, "f32x3": _lib.PREC_F32X3, "f32": _lib.PREC_F32}[self.det_precision]:
+            self.pipe = pipe                      # same weights, same arithmetic: share the handles (plans are keyed by shape)
+            self.pipe.cfg = self.cfg
+            self.pipe._layouts = {}
+        else:
+            self.pipe = pipeline.FramePipeline(ctx["det_w"], ctx["sr_w"], self.cfg, arch=args.arch, device=ctx["local_rank"],
+                                               det_precision={"f16": _lib.PREC_F16, "f32x3": _lib.PREC_F32X3, "f32": _lib.PREC_F32}[self.det_precision],
+                                               sr_half=True, rank=self.rank, world=self.world)
+        self.items_per_frame = pipeline.frame_items(self.H, self.W, self.cfg, 1).shape[0]
+        self.fixed_sizes = pipeline.sr_crop_sizes(max(args.sr_crops, 1), seed=0)
+        self.host_rows = torch.empty((self.cfg.merge_cap, self.pipe.stride), dtype=torch.float32).pin_memory()
+        self.host_sr = None
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        self.host_supers, self.slots = {}, {}
+        self.state, self.pending, self.queue, self.group = {}, {}, [], {}
+        self.sr_px = 0
+
+    # ---- frames: pinned host super-frames, three device slots per super-frame size, uploads on a copy stream ----------------
+    def host_super(self, nf, variant):
+        key = (nf, variant)
+        if key not in self.host_supers:
+            hf = self.ctx["host_frames"]
+            sf = np.concatenate([hf[(variant + f) % len(hf)] for f in range(nf)], 0)
+            self.host_supers[key] = self.torch.from_numpy(sf).pin_memory()
+        return self.host_supers[key]
+
+    def upload(self, gi, nf):
+        """Start the host->device copy of group gi's super-frame (only the rows this rank reads) on the copy stream."""
+        torch = self.torch
+        variant = gi % len(self.ctx["host_frames"])
+        if self.resident:
+            key = ("res", nf, variant)
+            if key not in self.slots:
+                self.slots[key] = self.host_super(nf, variant).to(self.dev)
+                torch.cuda.synchronize(self.dev)
+            return self.slots[key], None
+        key = (nf, gi % 3)
+        if key not in self.slots:
+            self.slots[key] = torch.empty((nf * self.H, self.W, 3), dtype=torch.uint8, device=self.dev)
+            torch.cuda.synchronize(self.dev)
+        slot, src = self.slots[key], self.host_super(nf, variant)
+        r0, r1 = self.pipe.layout(self.H, self.W, nf).rows_needed(self.rank, self.H)
+        ev = torch.cuda.Event()
+        if r1 > r0:
+            with torch.cuda.stream(self.copy_stream):
+                slot[r0:r1].copy_(src[r0:r1], non_blocking=True)
+                ev.record(self.copy_stream)
+        else:
+            ev.record(self.copy_stream)
+        self.state["upload_bytes"] = (r1 - r0) * self.W * 3
+        return slot, ev
+
+    # ---- super-resolution: crops of SB frames as one ragged batch on the enhancer's stream -------------------------------------
+    def crop_boxes(self, rows, frame_seed):
+        p, a = self.pipeline, self.args
+        if self.sr_sizes == "from-detections" and rows.shape[0] > 0:
+            b = rows[:a.sr_crops, :4].astype(np.int32)
+            b[:, 2] = np.maximum(b[:, 2], b[:, 0] + 4); b[:, 3] = np.maximum(b[:, 3], b[:, 1] + 4)     # enhance_image rejects < 4 px
+            return b
+        sizes = self.fixed_sizes if self.sr_sizes == "fixed" else p.sr_crop_sizes(a.sr_crops, seed=1000 + frame_seed)
+        return p.crop_boxes_for_sr(rows, self.H, self.W, a.sr_crops, sizes, seed=frame_seed)
+
+    def drain_sr(self):
+        if self.pending:
+            self.pipe.wait_sr()
+            out = self.pending.pop("out")
+            if self.host_sr is None or self.host_sr.numel() < out.numel():
+                self.host_sr = self.torch.empty((int(out.numel() * 1.5),), dtype=self.torch.uint8).pin_memory()
+            self.host_sr[:out.numel()].copy_(out)                  # enhanced crops -> host
+
+    def flush_sr(self, slot):
+        if not self.queue:
+            return
+        self.drain_sr()
+        q = [x for x in self.queue if len(x[1])]
+        self.queue.clear()
+        if not q:
+            return
+        out, offs = self.pipe.enhance_crops_multi([x[0] for x in q], self.H, self.W, [x[1] for x in q], slot=slot)
+        self.pending["out"] = out
+        self.sr_px += int(sum(int((b[:, 2] - b[:, 0]) @ (b[:, 3] - b[:, 1])) for _, b in q))
+
+    # ---- one group of DB steps ---------------------------------------------------------------------------------------------------
+    def groups(self, n_total):
+        return [(g0, min(self.DB, n_total - g0)) for g0 in range(0, n_total, self.DB)]
+
+    def run_group(self, gi, g0, gsz, n_total, nxt, profile):
+        """Detect the group's frames as one ragged batch (detector stream) while the next group's frames upload (copy stream) and the
+        previous frames' crops are enhanced (enhancer stream); then merge every frame and queue its crops."""
+        torch, pipe, a = self.torch, self.pipe, self.args
+        B, H, W = self.B, self.H, self.W
+        sf, ev = self.group.pop("next")
+        if nxt is not None:
+            self.group["next"] = self.upload(gi + 1, B * nxt[1])          # overlaps this group's detection
+        if ev is not None:
+            ev.synchronize()
+        if profile:
+            pipe.det.set_profile(True)
+        dets, counts, L, gathered = pipe.detect(sf, H, W, B * gsz, exchange=self.exchange)
+        if profile:
+            pipe.det.set_profile(False)
+        self.state["gathered"] = gathered
+        for i in range(g0, g0 + gsz):
+            last = profile and i == n_total - 1
+            for fb in range(B):
+                f = (i - g0) * B + fb
+                spread = L.owner(f) < 0                                                   # this frame's items live on several ranks
+                if not spread and L.owner(f) != self.rank:
+                    continue
+                if spread and not gathered:
+                    raise RuntimeError("frame items are spread over ranks but the exchange was disabled")
+                rows_d, n_d = pipe.merge_frame_of(dets, counts, L, f, gathered)      # replicated on every rank when spread (§8e)
+                n = pipe.merged_count(n_d)
+                self.host_rows[:n].copy_(rows_d[:n])                                   # merged detections -> host
+                rows = self.host_rows[:n].numpy().copy()
+                rows[:, [1, 3]] -= f * H
+                self.state["rows"] = rows
+                if a.sr_crops > 0:
+                    boxes = self.crop_boxes(rows, i * B + fb)
+                    self.state["boxes"] = boxes
+                    if spread:                                                          # crops of ONE frame over the ranks: LPT by area
+                        own = self.pipeline.lpt_assign((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]), self.world) == self.rank
+                        boxes = boxes[own]
+                    self.queue.append((sf[f * H:(f + 1) * H], boxes))
+            if a.sr_crops > 0 and (len(self.queue) >= self.SB or last):
+                if last:
+                    self.drain_sr()
+                    pipe.sr.set_profile(True)
+                self.flush_sr(slot=(i // self.SB) & 1)
+            if last:
+                self.drain_sr()
+                torch.cuda.synchronize(self.dev)
+                if pipe.sr is not None:
+                    pipe.sr.set_profile(False)
+
+    def loop(self, n_steps, profile_last=False):
+        gs = self.groups(n_steps)
+        self.group["next"] = self.upload(0, self.B * gs[0][1])
+        for gi, (g0, gsz) in enumerate(gs):
+            self.run_group(gi, g0, gsz, n_steps, gs[gi + 1] if gi + 1 < len(gs) else None, profile_last and gi == len(gs) - 1)
+        self.flush_sr(slot=0)
+        self.drain_sr()                                # the last frames' crops are part of the timed work
+
+    def barrier(self):
+        import torch.distributed as dist
+        self.torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def setup(self, warmup, steps):
+        """Untimed, like loading weights: lay out, tune and graph-capture the detector plan of every group size, and the enhancer plan of
+        every capacity bucket the loops will meet (a plan is keyed by capacity, not by crop sizes: a stream builds each bucket once)."""
+        for gsz in sorted({g[1] for n in (warmup, steps) for g in self.groups(n)}):
+            sf, ev = self.upload(0, self.B * gsz)
+            if ev is not None:
+                ev.synchronize()
+            for _ in range(3):
+                self.pipe.detect(sf, self.H, self.W, self.B * gsz, exchange=self.exchange)
+        self.loop(max(warmup, 2 * self.DB))
+        if self.args.sr_crops > 0:
+            self.loop(steps)                           # rehearsal with the timed loop's own crop sizes: every bucket it meets exists afterwards
+        self.sr_px = 0
+
+    def timed(self, warmup, steps, profile_last=True):
+        import torch.distributed as dist
+        self.setup(warmup, steps)
+        self.loop(warmup)
+        self.barrier()
+        self.sr_px = 0
+        t0 = time.perf_counter()
+        self.loop(steps, profile_last=profile_last)
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev if self.ctx["backend"] == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def describe(self):
+        a = self.args
+        return (f"{self.W}x{self.H} frame, YOLO11{a.arch}-pose (random-init), SAHI {a.slice}x{a.slice}/{a.overlap} ({self.items_per_frame - 1} slices + full frame), "
+                f"net input {self.imgsz}, conf {a.conf}, NMS 0.7, {self.pp_type}/IOS/0.5{'/agnostic' if self.class_agnostic else ''} merge"
+                + (f", Real-ESRGAN x4 on {a.sr_crops} crops/frame (sizes {self.sr_sizes})" if a.sr_crops > 0 else ", no SR"))
 
 
 def main():
@@ -101,7 +327,7 @@ def main():
     import torch
     import torch.distributed as dist
     import ffp_amd  # noqa: F401
-    from ffp_amd import _lib, pipeline, synth
+    from ffp_amd import _lib, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -120,172 +346,106 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    H, W, B = args.height, args.width, world
-    cfg = pipeline.PipeConfig(slice_h=args.slice, slice_w=args.slice, overlap=args.overlap, imgsz=args.imgsz, conf=args.conf,
-                              pp_type=args.pp_type, class_agnostic=args.class_agnostic, sr_crops=args.sr_crops)
-    det_w = synth.yolo11_pose_weights(args.arch)
-    sr_w = synth.rrdbnet_weights(4, 23) if args.sr_crops > 0 else None
-    pipe = pipeline.FramePipeline(det_w, sr_w, cfg, arch=args.arch, device=local_rank,
-                                  det_precision={"f16": _lib.PREC_F16, "f32x3": _lib.PREC_F32X3, "f32": _lib.PREC_F32}[args.det_precision], sr_half=True,
-                                  rank=rank, world=world)
+    H, W = args.height, args.width
+    ctx = {"rank": rank, "world": world, "local_rank": local_rank, "dev": dev, "backend": backend,
+           "det_w": synth.yolo11_pose_weights(args.arch), "sr_w": synth.rrdbnet_weights(4, 23) if args.sr_crops > 0 else None,
+           "host_frames": [synth.synthetic_frame(H, W, seed=i) for i in range(max(1, args.distinct_frames))]}
 
-    # synthetic frames, resident in HBM before the timed region. Detection runs on groups of DB consecutive steps: the
-    # B frames of each step of a group are stacked into one super-frame whose slices form ONE ragged batch (the small
-    # stride-16/32 layers of a single frame's 61 items do not fill 256 CUs: 6.8 -> 6.25 ms per frame at DB = 2).
-    DB = max(1, args.det_batch_frames)
-    host_frames = [synth.synthetic_frame(H, W, seed=i) for i in range(max(1, args.distinct_frames))]
-    supers = {}      # frames per super-frame -> list of resident stacks
+    main_r = Runner(args, ctx)
+    dt = main_r.timed(args.warmup, args.steps)
+    B = main_r.B
+    fps = B * args.steps / dt
+    pipe = main_r.pipe
+    prof = [dict(p, stage="det") for p in pipe.det.profile()]
+    if pipe.sr is not None:
+        prof += [dict(p, stage="sr") for p in pipe.sr.profile()]
+    prof.sort(key=lambda p: -p["ms"])
+    stage_ms = pipe.det.last_ms()
+    sr_ms = pipe.sr.last_ms() if pipe.sr is not None else None
+    sr_state = pipe.sr.plan_state() if pipe.sr is not None else None
+    det_graph = pipe.det.graph_status()
+    main_state = dict(main_r.state)
+    main_sr_px = main_r.sr_px
 
-    def stacks(nf):
-        if nf not in supers:
-            lst = []
-            for s_ in range(len(host_frames)):
-                sf_ = np.concatenate([host_frames[(s_ + f) % len(host_frames)] for f in range(nf)], 0)
-                lst.append(torch.from_numpy(sf_).to(dev))
-            supers[nf] = lst
-        return supers[nf]
+    # ---- secondary rows, measured in this same run (fewer steps): what the headline configuration is NOT ------------------------
+    secondary = {}
+    if not args.no_secondary:
+        ss, sw = max(2, args.secondary_steps), max(2, min(args.warmup, 4))
 
-    items_per_frame = pipeline.frame_items(H, W, cfg, 1).shape[0]
-    sizes = pipeline.sr_crop_sizes(max(args.sr_crops, 1), seed=0)
-    host_rows = torch.empty((cfg.merge_cap, pipe.stride), dtype=torch.float32).pin_memory()
-    sr_bytes = int(sum(((int(s) * 4) ** 2 * 3 + 15) // 16 * 16 for s in sizes[:args.sr_crops]))
-    host_sr = torch.empty((max(sr_bytes, 16) * max(args.sr_batch_frames, 1),), dtype=torch.uint8).pin_memory()
-    state = {}
+        def sec(name, **kw):
+            r = Runner(args, ctx, pipe=pipe, **kw)
+            d = r.timed(sw, ss, profile_last=False)
+            secondary[name] = {"value": round(r.B * ss / d, 3), "unit": "frames/s", "ms_per_step": round(d / ss * 1e3, 3), "steps": ss, "workload": r.describe(),
+                               "frames_per_step": r.B, "gathered": bool(r.state.get("gathered", False))}
+            return r
 
-    pending = {}     # super-resolution batch still running on the enhancer's stream
-    queue = []       # (frame tensor, crop boxes) of frames waiting for their SR batch
-
-    def drain_sr():
-        if pending:
-            pipe.wait_sr()
-            out = pending.pop("out")
-            host_sr[:out.numel()].copy_(out)                       # enhanced crops -> host
-
-    def flush_sr(slot):
-        """Enhance the queued frames' crops as ONE ragged batch (asynchronously, on the enhancer's stream)."""
-        if not queue:
-            return
-        drain_sr()
-        out, offs = pipe.enhance_crops_multi([q[0] for q in queue], H, W, [q[1] for q in queue], slot=slot)
-        pending["out"] = out
-        queue.clear()
-
-    group = {}
-
-    def step(i, n_total, profile=False):
-        """Frame(s) of step i. The first step of a group detects the whole group's frames (detector stream); every step
-        merges its own frames and queues their crops, which are enhanced on the enhancer's stream while later frames are
-        detected. The last group of the timed loop is the profiled one (per-launch events, eager launches)."""
-        g0 = (i // DB) * DB
-        gsz = min(DB, n_total - g0)                               # steps in this group
-        if i == g0:
-            sf = stacks(B * gsz)[(i // DB) % len(host_frames)]
-            if profile:
-                pipe.det.set_profile(True)
-            dets, counts, _ = pipe.detect(sf, H, W, B * gsz)
-            if profile:
-                pipe.det.set_profile(False)
-            group.update(sf=sf, dets=dets, counts=counts)
-        sf, dets, counts = group["sf"], group["dets"], group["counts"]
-        last = profile and i == n_total - 1
-        for fb in range(B):
-            f = (i - g0) * B + fb                                 # frame index inside the group's super-frame
-            if fb % world != rank:
-                continue
-            rows_d, n_d = pipe.merge_frame(dets, counts, f * items_per_frame, items_per_frame)
-            n = int(n_d.item())
-            host_rows[:n].copy_(rows_d[:n])                       # merged detections -> host
-            rows = host_rows[:n].numpy().copy()
-            rows[:, [1, 3]] -= f * H
-            state["rows"] = rows
-            if args.sr_crops > 0:
-                boxes = pipeline.crop_boxes_for_sr(rows, H, W, args.sr_crops, sizes, seed=i)
-                state["boxes"] = boxes
-                queue.append((sf[f * H:(f + 1) * H], boxes))
-                if len(queue) >= args.sr_batch_frames or last:
-                    if last:
-                        drain_sr()
-                        pipe.sr.set_profile(True)
-                    flush_sr(slot=(i // max(args.sr_batch_frames, 1)) & 1)
-        if last:
-            drain_sr()
-            torch.cuda.synchronize(dev)
-            if pipe.sr is not None:
-                pipe.sr.set_profile(False)
-
-    def barrier():
-        torch.cuda.synchronize(dev)
+        sec("frames_resident_in_hbm", resident=True)
+        if args.sr_crops > 0 and args.sr_sizes != "fixed":
+            sec("sr_sizes_fixed", sr_sizes="fixed")
+        sec("merge_nms_ios_agnostic", pp_type="NMS", class_agnostic=True)
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    # untimed setup: build (and graph-capture) the detector plan of every group size the loops below will meet
-    for gsz in sorted({min(DB, n - g0) for n in (args.warmup, args.steps) for g0 in range(0, n, DB)}):
-        for _ in range(2):
-            pipe.detect(stacks(B * gsz)[0], H, W, B * gsz)
-    for i in range(args.warmup):
-        step(i, args.warmup)
-    flush_sr(slot=0)
-    drain_sr()
-    barrier()
-    last_g0 = ((args.steps - 1) // DB) * DB
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, args.steps, profile=(i >= last_g0))   # the last group also brackets every conv launch with HIP events
-    flush_sr(slot=0)
-    drain_sr()                                      # the last frames' crops are part of the timed work
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+            if not main_state.get("gathered", False):
+                sec("with_allgather", exchange="always")
+            if main_r.B != 1:
+                r = sec("one_frame_across_ranks", frames_per_step=1, exchange="auto")
+                secondary["one_frame_across_ranks"]["scaling"] = "strong"
+        if args.imgsz != 1024:
+            sec("image_size_1024_reference_default", imgsz=1024)
+        if args.det_precision != "f32":
+            sec("detector_exact_f32", det_precision="f32")
 
     if rank == 0:
-        fps = B * args.steps / dt
-        prof = [dict(p, stage="det") for p in pipe.det.profile()]
-        if pipe.sr is not None:
-            prof += [dict(p, stage="sr") for p in pipe.sr.profile()]
-        prof.sort(key=lambda p: -p["ms"])
         roof = None
         pmc = {}
-        try:    # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), keyed by kernel variant
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                pmc = json.load(fh).get("kernels", {})
-        except Exception:
-            pmc = {}
+        pmc_src = None
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # HBM bytes per launch from the committed PMC passes, keyed by kernel variant
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    pmc = json.load(fh).get("kernels", {})
+                pmc_src = name
+                break
+            except Exception:
+                pmc = {}
         if prof:
             d = prof[0]
             dtp = d["variant"].split("_")[0]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": f"{'conv_rows_kernel' if d['variant'].endswith('_rows') else 'conv_mfma_kernel'}<{d['variant']}> ({d['stage']})", "achieved": round(ach, 2),
+            kname = "conv_rows_kernel" if "_rows" in d["variant"] else "conv_mfma_kernel"
+            roof = {"bound": "mfma", "kernel": f"{kname}<{d['variant']}> ({d['stage']})", "achieved": round(ach, 2),
                     "peak": PEAK_TFLOPS[dtp], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtp], 4),
                     "traffic": (round(pmc[d["variant"]]["hbm_bytes_per_launch"]) if d["variant"] in pmc else None),
-                    "traffic_source": ("profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if d["variant"] in pmc else None),
+                    "traffic_source": (f"profiles/{pmc_src} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if d["variant"] in pmc else None),
                     "launches": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2),
                     "flops_per_launch": d["flops"] / max(d["launches"], 1)}
-        stage_ms = pipe.det.last_ms()
         res = {
             "metric": "end-to-end 4K frames/sec (SAHI+YOLOv11s+ESRGAN×4)", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if (world > 1 and B == 1) else "weak", "vs_baseline": None,
             "dtype": f"{args.det_precision}(detect)+f16(sr)" if args.sr_crops > 0 else args.det_precision, "data": "synthetic",
-            "config": {"workload": f"{W}x{H} frame, YOLO11{args.arch}-pose (random-init), SAHI {args.slice}x{args.slice}/{args.overlap} "
-                                   f"({items_per_frame - 1} slices + full frame), net input {args.imgsz}, conf {args.conf}, NMS 0.7, "
-                                   f"{args.pp_type}/IOS/0.5{'/agnostic' if args.class_agnostic else ''} merge" + (f", Real-ESRGAN x4 on {args.sr_crops} crops/frame "
-                                   f"({int((sizes[:args.sr_crops] ** 2).sum())} px)" if args.sr_crops > 0 else ", no SR"),
-                       "frames_per_step": B, "det_batch_frames": DB, "sr_batch_frames": args.sr_batch_frames, "parallelism": f"items sharded over {world} rank(s), 1 all-gather" if world > 1 else "single GPU",
-                       "detections_last_frame": int(state.get("rows", np.zeros((0, 1))).shape[0])},
+            "config": {"workload": main_r.describe(),
+                       "span": ("frames resident in HBM -> results in host memory" if main_r.resident else
+                                "frame in pinned host memory -> upload (copy stream) -> detect -> merge -> SR -> detections + enhanced crops in host memory"),
+                       "frames_per_step": B, "det_batch_frames": main_r.DB, "sr_batch_frames": main_r.SB,
+                       "parallelism": (f"items of {B} frame(s) in {world} contiguous cost-balanced blocks; "
+                                       + ("one all-gather per group" if main_state.get("gathered") else "whole frames per rank: no exchange needed")) if world > 1 else "single GPU",
+                       "upload_bytes_per_group_per_rank": int(main_state.get("upload_bytes", 0)),
+                       "sr_px_per_frame_mean": round(main_sr_px * world / max(args.steps * B, 1), 1),
+                       "detections_last_frame": int(main_state.get("rows", np.zeros((0, 1))).shape[0]),
+                       "det_graph_status": det_graph, "sr_plan_state": sr_state},
             "stage_ms_last_call": {k: round(v, 3) for k, v in stage_ms.items()},
-            "sr_ms_last_call": round(pipe.sr.last_ms(), 3) if pipe.sr is not None else None,
+            "sr_ms_last_call": round(sr_ms, 3) if sr_ms is not None else None,
             "conv_profile_last_step": [{"kernel": p["variant"], "stage": p["stage"], "ms": round(p["ms"], 3), "launches": p["launches"],
                                         "tflops": round(p["flops"] / max(p["ms"], 1e-9) / 1e9, 2)} for p in prof],
             "roofline": roof,
+            "secondary": secondary,
         }
         if world == 1 and not args.no_cpu_baseline:
-            d, c, _ = pipe.detect(stacks(1)[0][:H], H, W, 1)
+            base_r = Runner(args, ctx, pipe=pipe, resident=True)
+            sf, _ = base_r.upload(0, 1)
+            d, c, _, _ = pipe.detect(sf, H, W, 1)
             pre = torch.cat([d[k, :int(c[k])] for k in range(d.shape[0])], 0).cpu().numpy()
-            res["cpu_baseline"] = cpu_baseline(args, det_w, sr_w, host_frames[0], state.get("boxes", np.zeros((0, 4), np.int32)), pre)
+            boxes = main_state.get("boxes", np.zeros((0, 4), np.int32))
+            res["cpu_baseline"] = cpu_baseline(args, ctx["det_w"], ctx["sr_w"], ctx["host_frames"][0], boxes, pre)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -75,13 +75,15 @@ _SIGS = {
     "ffp_sr_enhance_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ffp_sr_enhance_batch": (C.c_int, [C.c_void_p, C.c_int, _p(C.c_void_p), _p(C.c_int32), _p(C.c_int32), C.c_int, C.c_int, C.c_int,
                                        _p(C.c_void_p)]),
-    "ffp_sr_enhance_crops_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _p(C.c_int32), C.c_int, C.c_void_p, C.c_size_t,
-                                           _p(C.c_int64)]),
-    "ffp_sr_enhance_crops_dev_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _p(C.c_int32), C.c_int, C.c_void_p, C.c_size_t,
-                                                 _p(C.c_int64)]),
+    "ffp_sr_enhance_crops_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _p(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_size_t, _p(C.c_int64)]),
+    "ffp_sr_enhance_crops_dev_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _p(C.c_int32), C.c_int, C.c_int, C.c_int,
+                                                 C.c_void_p, C.c_size_t, _p(C.c_int64)]),
     "ffp_sr_wait": (C.c_int, [C.c_void_p]),
     "ffp_sr_enhance_crops_multi_dev_async": (C.c_int, [C.c_void_p, C.c_int, _p(C.c_void_p), _p(C.c_int32), C.c_int, C.c_int, _p(C.c_int32),
-                                                       C.c_int, C.c_void_p, C.c_size_t, _p(C.c_int64)]),
+                                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _p(C.c_int64)]),
+    "ffp_sr_plan_state": (C.c_int, [C.c_void_p, _p(C.c_int32), _p(C.c_int32)]),
+    "ffp_det_graph_status": (C.c_int, [C.c_void_p, _p(C.c_int32)]),
     "ffp_sr_last_ms": (C.c_int, [C.c_void_p, _p(C.c_float)]),
     "ffp_sr_last_conv_stats": (C.c_int, [C.c_void_p, _p(C.c_double), _p(C.c_float), _p(C.c_int32)]),
     "ffp_sr_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
@@ -103,14 +105,20 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m ffp_amd.build` "
                                "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.")
-        # A process that also uses torch's device runtime must bring that one up FIRST: PyTorch-ROCm wheels carry their own
-        # copy of the HIP runtime, and once libffp.so has initialised the system copy torch reports "No HIP GPUs are available"
-        # (the other order works; observed on ROCm 7.2 + torch 2.10/rocm7.0).
-        if "torch" in sys.modules:
+        # ONE HIP runtime per process. libffp.so needs `libamdhip64.so.7` and the PyTorch-ROCm wheel bundles a library with
+        # that very SONAME (torch/lib/libamdhip64.so, with its own libhsa-runtime64 / librccl next to it): the dynamic loader
+        # binds every later user to whichever copy was mapped first. If the system copy (/opt/rocm) came first, a later
+        # `import torch` would run the wheel's libraries on a runtime they were not built with (observed: "No HIP GPUs are
+        # available"). So when a torch wheel is installed its copy is mapped first — whether or not torch has been imported —
+        # and libffp.so, torch and RCCL then share one runtime, one set of device contexts and one allocator view
+        # (tests/test_host_logic.py::test_single_hip_runtime checks both load orders).
+        if "torch" not in sys.modules:
             try:
-                t = sys.modules["torch"]
-                if t.cuda.is_available() and not t.cuda.is_initialized():
-                    t.cuda.init()
+                import importlib.util
+                spec = importlib.util.find_spec("torch")
+                cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
+                if cand and os.path.exists(cand):
+                    C.CDLL(cand, mode=C.RTLD_GLOBAL)
             except Exception:
                 pass
         l = C.CDLL(LIB_PATH)
@@ -258,6 +266,12 @@ class Detector:
             out[k] = v.value
         return out
 
+    def graph_status(self) -> int:
+        """1: the last call replayed a captured hipGraph, 0: not captured yet, -1: capture failed (eager launches)."""
+        v = C.c_int32(0)
+        _check(lib().ffp_det_graph_status(self._h, C.byref(v)))
+        return v.value
+
     def set_profile(self, on: bool):
         _check(lib().ffp_det_set_profile(self._h, int(on)))
 
@@ -350,10 +364,41 @@ class Enhancer:
         _check(lib().ffp_sr_enhance_batch(self._h, n, ip, _ip(hs), _ip(ws), tile, tile_pad, pre_pad, op))
         return outs
 
+    def enhance_crops_dev(self, d_frames: Sequence[int], H: int, W: int, boxes: np.ndarray, d_out: int, out_cap: int,
+                          frame_of_box: Optional[np.ndarray] = None, tile: int = 400, tile_pad: int = 10, wait: bool = True) -> np.ndarray:
+        """Crops of resident BGR frame(s) (device pointers) -> enhanced crops packed in device memory at d_out.
+        One frame: ffp_sr_enhance_crops_dev (wait) / _dev_async; several: ffp_sr_enhance_crops_multi_dev_async (+ ffp_sr_wait when
+        wait). Returns the n+1 byte offsets (a crop that is empty after clamping has a zero-length entry)."""
+        b = np.ascontiguousarray(boxes, np.int32).reshape(-1, 4)
+        n = b.shape[0]
+        offs = np.zeros(n + 1, np.int64)
+        op = offs.ctypes.data_as(_p(C.c_int64))
+        if len(d_frames) == 1 and frame_of_box is None:
+            fn = lib().ffp_sr_enhance_crops_dev if wait else lib().ffp_sr_enhance_crops_dev_async
+            _check(fn(self._h, d_frames[0], H, W, _ip(b), n, tile, tile_pad, d_out, out_cap, op))
+        else:
+            f = np.ascontiguousarray(frame_of_box if frame_of_box is not None else np.zeros(n, np.int32), np.int32)
+            ptrs = (C.c_void_p * len(d_frames))(*d_frames)
+            _check(lib().ffp_sr_enhance_crops_multi_dev_async(self._h, len(d_frames), ptrs, _ip(f), H, W, _ip(b), n, tile, tile_pad, d_out,
+                                                              out_cap, op))
+            if wait:
+                self.wait()
+        return offs
+
+    def wait(self):
+        _check(lib().ffp_sr_wait(self._h))
+
     def last_ms(self) -> float:
         v = C.c_float(0)
         _check(lib().ffp_sr_last_ms(self._h, C.byref(v)))
         return v.value
+
+    def plan_state(self) -> dict:
+        """plans_built: network layouts built so far (capacity-keyed: varying crop sizes must not grow it);
+        last_graph: the last call replayed a captured hipGraph."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        _check(lib().ffp_sr_plan_state(self._h, C.byref(a), C.byref(b)))
+        return {"plans_built": a.value, "last_graph": bool(b.value)}
 
     def set_profile(self, on: bool):
         _check(lib().ffp_sr_set_profile(self._h, int(on)))

@@ -64,7 +64,7 @@ void upload_frame(DetEngine& e, const uint8_t* frame, int H, int W) {
 extern "C" {
 
 const char* ffp_last_error(void) { return ffp::last_error().c_str(); }
-int ffp_version(void) { return 100; }
+int ffp_version(void) { return 200; }
 
 int ffp_device_count(int* out_n) {
   FFP_API_BEGIN
@@ -226,8 +226,9 @@ int ffp_sliced_predict(ffp_det* d, const uint8_t* frame, int H, int W, int chan_
               e.scratch_out.as<float>(), nullptr, cap, e.scratch_outn.as<int32_t>());
   int k = 0;
   FFP_HIP(hipMemcpy(&k, e.scratch_outn.p, sizeof(int), hipMemcpyDeviceToHost));
-  FFP_HIP(hipMemcpy(out, e.scratch_out.p, sizeof(float) * (size_t)k * stride, hipMemcpyDeviceToHost));
   *out_n = k;
+  FFP_CHECK(k <= cap, FFP_ERR_ARG, "sliced_predict: %d merged detections exceed the output capacity %d (nothing was dropped silently: call again with cap >= %d)", k, cap, k);
+  FFP_HIP(hipMemcpy(out, e.scratch_out.p, sizeof(float) * (size_t)k * stride, hipMemcpyDeviceToHost));
   FFP_API_END
 }
 
@@ -241,6 +242,13 @@ int ffp_det_stage_dev(ffp_det* d, const uint8_t* d_frame, int H, int W, int chan
         world, d_local_dets, d_local_counts, &nl, &nt);
   *out_n_local = nl;
   *out_n_total = nt;
+  FFP_API_END
+}
+
+int ffp_det_graph_status(ffp_det* d, int32_t* out_state) {
+  FFP_API_BEGIN
+  FFP_CHECK(d && out_state, FFP_ERR_ARG, "null argument");
+  *out_state = d->eng.last_graph_state;
   FFP_API_END
 }
 
@@ -333,51 +341,63 @@ int ffp_sr_enhance(ffp_sr* s, const uint8_t* bgr, int h, int w, int tile, int ti
 
 // crops of one or several resident frames (frame_of_box == nullptr: all from d_frames[0]) -> one ragged SR batch
 static int sr_crops_impl(ffp_sr* s, int n_frames, const uint8_t* const* d_frames, const int32_t* frame_of_box, int H, int W,
-                         const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap, int64_t* out_offsets, bool wait) {
+                         const int32_t* boxes, int n, int tile, int tile_pad, uint8_t* d_out, size_t out_cap, int64_t* out_offsets, bool wait) {
   FFP_API_BEGIN
   FFP_CHECK(s && d_frames && n_frames > 0 && boxes && n > 0 && d_out && out_offsets, FFP_ERR_ARG, "bad argument");
   SrEngine& e = s->eng;
   FFP_HIP(hipSetDevice(e.device()));
   e.wait_done();                      // one enhancement in flight per handle: its scratch and plan tables are about to be reused
   const int sc = e.scale();
-  std::vector<SrImage> v(n);
-  std::vector<int4> hb(n);
-  std::vector<long long> offs(n);
+  std::vector<SrImage> v;
+  v.reserve(n);
+  // box / offset tables go through pinned staging so that the uploads are asynchronous on the enhancer's stream
+  e.crop_stage.ensure((sizeof(int4) + sizeof(long long)) * (size_t)n);
+  int4* hb = reinterpret_cast<int4*>(e.crop_stage.p);
+  long long* offs = reinterpret_cast<long long*>(hb + n);
+  std::vector<int> fidx;
   size_t in_tot = 0, out_tot = 0;
   for (int i = 0; i < n; ++i) {
     const int fi = frame_of_box ? frame_of_box[i] : 0;
     FFP_CHECK(fi >= 0 && fi < n_frames && d_frames[fi], FFP_ERR_ARG, "crop %d refers to frame %d of %d", i, fi, n_frames);
-    // utils/visualization.py:204-213: int box, clamp to the frame, skip empty
-    int x1 = std::max(0, boxes[4 * i]), y1 = std::max(0, boxes[4 * i + 1]);
-    int x2 = std::min(W, boxes[4 * i + 2]), y2 = std::min(H, boxes[4 * i + 3]);
-    FFP_CHECK(x2 > x1 && y2 > y1, FFP_ERR_ARG, "crop %d is empty after clamping", i);
-    const int w = x2 - x1, h = y2 - y1;
-    hb[i] = make_int4(x1, y1, w, h);
-    offs[i] = (long long)in_tot;
-    v[i].in_off = (long long)in_tot; v[i].in_stride = w * 3; v[i].h = h; v[i].w = w;
-    v[i].out_off = (long long)out_tot; v[i].out_stride = w * sc * 3;
+    // utils/visualization.py:204-213: int box, clamp to the frame; an empty crop is skipped (`if face_crop.size > 0`),
+    // here: a zero-length entry in out_offsets
+    const int x1 = std::max(0, boxes[4 * i]), y1 = std::max(0, boxes[4 * i + 1]);
+    const int x2 = std::min(W, boxes[4 * i + 2]), y2 = std::min(H, boxes[4 * i + 3]);
     out_offsets[i] = (int64_t)out_tot;
+    if (x2 <= x1 || y2 <= y1) continue;
+    const int w = x2 - x1, h = y2 - y1;
+    const int k = (int)v.size();
+    hb[k] = make_int4(x1, y1, w, h);
+    offs[k] = (long long)in_tot;
+    fidx.push_back(fi);
+    SrImage im;
+    im.in_off = (long long)in_tot; im.in_stride = w * 3; im.h = h; im.w = w;
+    im.out_off = (long long)out_tot; im.out_stride = w * sc * 3;
+    v.push_back(im);
     in_tot += ((size_t)h * w * 3 + 15) / 16 * 16;
     out_tot += ((size_t)h * sc * w * sc * 3 + 15) / 16 * 16;
   }
   out_offsets[n] = (int64_t)out_tot;
   FFP_CHECK(out_tot <= out_cap, FFP_ERR_ARG, "output needs %zu bytes, capacity %zu", out_tot, out_cap);
+  const int m = (int)v.size();
+  if (m == 0) return FFP_OK;          // every crop was empty: nothing to enhance
   e.scratch_in.ensure(in_tot);
-  e.scratch_boxes.ensure(sizeof(int4) * n);
-  e.scratch_offs.ensure(sizeof(long long) * n);
-  FFP_HIP(hipMemcpyAsync(e.scratch_boxes.p, hb.data(), sizeof(int4) * n, hipMemcpyHostToDevice, e.stream()));
-  FFP_HIP(hipMemcpyAsync(e.scratch_offs.p, offs.data(), sizeof(long long) * n, hipMemcpyHostToDevice, e.stream()));
+  e.scratch_boxes.ensure(sizeof(int4) * m);
+  e.scratch_offs.ensure(sizeof(long long) * m);
+  // the offsets sit behind n (not m) boxes in the staging block
+  FFP_HIP(hipMemcpyAsync(e.scratch_boxes.p, hb, sizeof(int4) * m, hipMemcpyHostToDevice, e.stream()));
+  FFP_HIP(hipMemcpyAsync(e.scratch_offs.p, offs, sizeof(long long) * m, hipMemcpyHostToDevice, e.stream()));
   // boxes are gathered frame by frame (contiguous runs of equal frame index)
-  for (int i0 = 0; i0 < n;) {
-    const int fi = frame_of_box ? frame_of_box[i0] : 0;
+  for (int i0 = 0; i0 < m;) {
+    const int fi = fidx[i0];
     int i1 = i0 + 1;
-    while (i1 < n && (frame_of_box ? frame_of_box[i1] : 0) == fi) ++i1;
+    while (i1 < m && fidx[i1] == fi) ++i1;
     launch_crop_gather(d_frames[fi], W, e.scratch_boxes.as<int4>() + i0, e.scratch_offs.as<long long>() + i0, i1 - i0,
                        e.scratch_in.as<uint8_t>(), e.stream());
     i0 = i1;
   }
-  FFP_HIP(hipStreamSynchronize(e.stream()));
-  e.enhance_dev(e.scratch_in.as<uint8_t>(), d_out, v, 0, 10, 0, wait);
+  // FaceEnhancer enhances every crop with its tile setting (tile 400 / pad 10: utils/enhancer.py:21,135-142,214)
+  e.enhance_dev(e.scratch_in.as<uint8_t>(), d_out, v, tile, tile_pad, 0, wait);
   FFP_API_END
 }
 
@@ -392,19 +412,19 @@ int ffp_sr_enhance_dev(ffp_sr* s, const uint8_t* d_bgr, int h, int w, int tile, 
   FFP_API_END
 }
 
-int ffp_sr_enhance_crops_dev(ffp_sr* s, const uint8_t* d_frame, int H, int W, const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap,
-                             int64_t* out_offsets) {
-  return sr_crops_impl(s, 1, &d_frame, nullptr, H, W, boxes, n, d_out, out_cap, out_offsets, true);
+int ffp_sr_enhance_crops_dev(ffp_sr* s, const uint8_t* d_frame, int H, int W, const int32_t* boxes, int n, int tile, int tile_pad, uint8_t* d_out,
+                             size_t out_cap, int64_t* out_offsets) {
+  return sr_crops_impl(s, 1, &d_frame, nullptr, H, W, boxes, n, tile, tile_pad, d_out, out_cap, out_offsets, true);
 }
 
-int ffp_sr_enhance_crops_dev_async(ffp_sr* s, const uint8_t* d_frame, int H, int W, const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap,
-                                   int64_t* out_offsets) {
-  return sr_crops_impl(s, 1, &d_frame, nullptr, H, W, boxes, n, d_out, out_cap, out_offsets, false);
+int ffp_sr_enhance_crops_dev_async(ffp_sr* s, const uint8_t* d_frame, int H, int W, const int32_t* boxes, int n, int tile, int tile_pad,
+                                   uint8_t* d_out, size_t out_cap, int64_t* out_offsets) {
+  return sr_crops_impl(s, 1, &d_frame, nullptr, H, W, boxes, n, tile, tile_pad, d_out, out_cap, out_offsets, false);
 }
 
 int ffp_sr_enhance_crops_multi_dev_async(ffp_sr* s, int n_frames, const uint8_t* const* d_frames, const int32_t* frame_of_box, int H, int W,
-                                         const int32_t* boxes, int n, uint8_t* d_out, size_t out_cap, int64_t* out_offsets) {
-  return sr_crops_impl(s, n_frames, d_frames, frame_of_box, H, W, boxes, n, d_out, out_cap, out_offsets, false);
+                                         const int32_t* boxes, int n, int tile, int tile_pad, uint8_t* d_out, size_t out_cap, int64_t* out_offsets) {
+  return sr_crops_impl(s, n_frames, d_frames, frame_of_box, H, W, boxes, n, tile, tile_pad, d_out, out_cap, out_offsets, false);
 }
 
 int ffp_sr_wait(ffp_sr* s) {
@@ -412,6 +432,13 @@ int ffp_sr_wait(ffp_sr* s) {
   FFP_CHECK(s, FFP_ERR_ARG, "null handle");
   s->eng.wait_done();
   FFP_API_END
+}
+
+int ffp_sr_plan_state(ffp_sr* s, int32_t* out_plans_built, int32_t* out_last_graph) {
+  if (!s) return FFP_ERR_ARG;
+  if (out_plans_built) *out_plans_built = s->eng.plans_built;
+  if (out_last_graph) *out_last_graph = s->eng.last_graph ? 1 : 0;
+  return FFP_OK;
 }
 
 int ffp_sr_last_ms(ffp_sr* s, float* out_ms) { if (!s || !out_ms) return FFP_ERR_ARG; *out_ms = s->eng.last_ms; return FFP_OK; }

@@ -17,8 +17,13 @@ void fail(int code, const char* fmt, ...) {
   throw Error(code, buf);
 }
 
+Level::~Level() {
+  if (stage) (void)hipHostFree(stage);
+}
+
 void Level::build(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st) {
   FFP_CHECK(hs.size() == ws.size() && !hs.empty(), FFP_ERR_ARG, "level: empty batch");
+  FFP_CHECK(!capacity(), FFP_ERR_STATE, "level: build() on a capacity-mode level (use assign)");
   n = (int)hs.size();
   h = hs; w = ws;
   off.resize(n);
@@ -37,26 +42,117 @@ void Level::build(const std::vector<int>& hs, const std::vector<int>& ws, hipStr
   tiles.clear();
 }
 
+void Level::reserve(int cap_n, int64_t cap_px, int cap_tiles16, hipStream_t st) {
+  FFP_CHECK(cap_n > 0 && cap_px > 0 && cap_tiles16 > 0, FFP_ERR_ARG, "level: empty capacity");
+  FFP_CHECK(cap_px < (int64_t)1 << 31, FFP_ERR_ARG, "level: capacity of %lld pixels exceeds the 2^31 table limit", (long long)cap_px);
+  (void)st;
+  n = cap_n; total_px = cap_px; cap_t16 = cap_tiles16;
+  act_n = 0; act_px = 0;
+  h.assign(n, 0); w.assign(n, 0); off.assign(n, 0);
+  d_tab.alloc(sizeof(int4) * n);
+  tiles.clear();
+  // staging: the image table + tile tables of heights 16 and 8 (grown if another height shows up)
+  stage_bytes = sizeof(int4) * ((size_t)n + (size_t)tile_cap(cap_t16, 16) + (size_t)tile_cap(cap_t16, 8) + 8);
+  if (stage) { (void)hipHostFree(stage); stage = nullptr; }
+  FFP_HIP(hipHostMalloc(&stage, stage_bytes, hipHostMallocDefault));
+}
+
+void Level::fill_tiles(int th, TileTab& t, hipStream_t st, size_t* stage_off) {
+  // capacity mode: tile rows of the current batch -> staging -> device (only the real entries; kernels bound on d_count)
+  int4* dst = reinterpret_cast<int4*>(static_cast<unsigned char*>(stage) + *stage_off);
+  int k = 0;
+  for (int i = 0; i < act_n; ++i)
+    for (int y = 0; y < h[i]; y += th)
+      for (int x = 0; x < w[i]; x += 16) {
+        FFP_CHECK(k < t.cap, FFP_ERR_STATE, "level: batch needs more than %d tiles of height %d", t.cap, th);
+        dst[k++] = make_int4(i, y, x, 0);
+      }
+  dst[k] = make_int4(k, 0, 0, 0);          // the count travels right behind the entries
+  t.n = k;
+  if (k > 0) FFP_HIP(hipMemcpyAsync(t.tab.p, dst, sizeof(int4) * k, hipMemcpyHostToDevice, st));
+  FFP_HIP(hipMemcpyAsync(t.d_count.p, dst + k, sizeof(int), hipMemcpyHostToDevice, st));
+  *stage_off += sizeof(int4) * ((size_t)k + 1);
+}
+
+void Level::assign(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st) {
+  FFP_CHECK(capacity(), FFP_ERR_STATE, "level: assign() needs reserve()");
+  FFP_CHECK(hs.size() == ws.size() && !hs.empty(), FFP_ERR_ARG, "level: empty batch");
+  FFP_CHECK((int)hs.size() <= n, FFP_ERR_ARG, "level: %d images exceed the capacity of %d", (int)hs.size(), n);
+  act_n = (int)hs.size();
+  int64_t px = 0;
+  long long t16 = 0;
+  for (int i = 0; i < n; ++i) {
+    if (i < act_n) {
+      FFP_CHECK(hs[i] > 0 && ws[i] > 0, FFP_ERR_ARG, "level: image %d has size %dx%d", i, ws[i], hs[i]);
+      h[i] = hs[i]; w[i] = ws[i]; off[i] = px;
+      px += (int64_t)hs[i] * ws[i];
+      t16 += (long long)((hs[i] + 15) / 16) * ((ws[i] + 15) / 16);
+    } else {
+      h[i] = 0; w[i] = 0;
+    }
+  }
+  FFP_CHECK(px <= total_px && t16 <= cap_t16, FFP_ERR_ARG, "level: batch of %lld px / %lld tiles exceeds the capacity (%lld px / %d tiles)",
+            (long long)px, t16, (long long)total_px, cap_t16);
+  act_px = px;
+  size_t need = sizeof(int4) * ((size_t)n + 8);
+  for (auto& kv : tiles) need += sizeof(int4) * ((size_t)kv.second.cap + 1);
+  if (need > stage_bytes) {
+    FFP_HIP(hipStreamSynchronize(st));
+    (void)hipHostFree(stage);
+    stage = nullptr;
+    stage_bytes = need;
+    FFP_HIP(hipHostMalloc(&stage, stage_bytes, hipHostMallocDefault));
+  }
+  int4* tab = reinterpret_cast<int4*>(stage);
+  for (int i = 0; i < n; ++i) {
+    if (i >= act_n) off[i] = px;            // padding entries: zero-sized images behind the last real pixel
+    tab[i] = make_int4((int)off[i], h[i], w[i], 0);
+  }
+  FFP_HIP(hipMemcpyAsync(d_tab.p, tab, sizeof(int4) * n, hipMemcpyHostToDevice, st));
+  size_t so = sizeof(int4) * (size_t)n;
+  for (auto& kv : tiles) fill_tiles(kv.first, kv.second, st, &so);
+}
+
 long long Level::count_tiles(int th) const {
   long long t = 0;
   for (int i = 0; i < n; ++i) t += (long long)((h[i] + th - 1) / th) * ((w[i] + 15) / 16);
   return t;
 }
 
-const int4* Level::tile_table(int th, int* n_tiles, hipStream_t st) {
+const int4* Level::tile_table(int th, int* n_launch, const int** d_count, hipStream_t st) {
   auto it = tiles.find(th);
   if (it == tiles.end()) {
-    std::vector<int4> t;
-    for (int i = 0; i < n; ++i)
-      for (int y = 0; y < h[i]; y += th)
-        for (int x = 0; x < w[i]; x += 16) t.push_back(make_int4(i, y, x, 0));
-    DevBuf b(sizeof(int4) * t.size());
-    FFP_HIP(hipMemcpyAsync(b.p, t.data(), sizeof(int4) * t.size(), hipMemcpyHostToDevice, st));
-    FFP_HIP(hipStreamSynchronize(st));
-    it = tiles.emplace(th, std::make_pair(std::move(b), (int)t.size())).first;
+    TileTab t;
+    if (capacity()) {
+      // first use of this tile height: allocate at capacity and fill from the current batch (synchronously: rare)
+      t.cap = tile_cap(cap_t16, th);
+      t.tab.alloc(sizeof(int4) * (size_t)t.cap);
+      t.d_count.alloc(sizeof(int));
+      std::vector<int4> v;
+      for (int i = 0; i < act_n; ++i)
+        for (int y = 0; y < h[i]; y += th)
+          for (int x = 0; x < w[i]; x += 16) v.push_back(make_int4(i, y, x, 0));
+      FFP_CHECK((int)v.size() <= t.cap, FFP_ERR_STATE, "level: batch needs more than %d tiles of height %d", t.cap, th);
+      t.n = (int)v.size();
+      if (t.n > 0) FFP_HIP(hipMemcpyAsync(t.tab.p, v.data(), sizeof(int4) * v.size(), hipMemcpyHostToDevice, st));
+      FFP_HIP(hipMemcpyAsync(t.d_count.p, &t.n, sizeof(int), hipMemcpyHostToDevice, st));
+      FFP_HIP(hipStreamSynchronize(st));
+    } else {
+      std::vector<int4> v;
+      for (int i = 0; i < n; ++i)
+        for (int y = 0; y < h[i]; y += th)
+          for (int x = 0; x < w[i]; x += 16) v.push_back(make_int4(i, y, x, 0));
+      t.tab.alloc(sizeof(int4) * v.size());
+      FFP_HIP(hipMemcpyAsync(t.tab.p, v.data(), sizeof(int4) * v.size(), hipMemcpyHostToDevice, st));
+      FFP_HIP(hipStreamSynchronize(st));
+      t.n = (int)v.size();
+    }
+    it = tiles.emplace(th, std::move(t)).first;
   }
-  *n_tiles = it->second.second;
-  return it->second.first.as<int4>();
+  const TileTab& t = it->second;
+  *n_launch = capacity() ? t.cap : t.n;
+  if (d_count) *d_count = capacity() ? t.d_count.as<int>() : nullptr;
+  return t.tab.as<int4>();
 }
 
 const int* Level::up2_map(const Level* src, hipStream_t st) {

@@ -65,24 +65,75 @@ struct DevBuf {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// pinned host memory (asynchronous uploads of small per-call tables)
+struct HostPinned {
+  void* p = nullptr;
+  size_t n = 0;
+  HostPinned() = default;
+  HostPinned(const HostPinned&) = delete;
+  HostPinned& operator=(const HostPinned&) = delete;
+  ~HostPinned() { if (p) (void)hipHostFree(p); }
+  void ensure(size_t bytes) {
+    if (bytes <= n) return;
+    if (p) { (void)hipHostFree(p); p = nullptr; n = 0; }
+    FFP_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    n = bytes;
+  }
+};
+
 // ---- a batch of images at one resolution ("level") -------------------------------------------------------
 // Activations are NHWC; the images of a batch may differ in size (ragged) and are stored back to back, so a level is
 // a table {pixel offset, h, w} per image. 1x1 convolutions see one flat pixel array; 3x3 ones walk a tile table.
+//
+// Two modes. build(): the level describes exactly one batch shape (detector: the slice grid of a resolution is fixed).
+// reserve() + assign(): CAPACITY mode (super-resolution: every frame brings a new multiset of crop sizes) — device
+// tables and every buffer sized from the level are allocated once for `cap_n` images / `cap_px` pixels / `cap_t16`
+// 16x16 tiles, and assign() refills the tables in place for each batch that fits. `n` / `total_px` then hold the
+// CAPACITY (they size buffers and flat launches: a captured launch sequence stays valid for every batch), the padding
+// entries of the image table are {total actual pixels, 0, 0} so flat-pixel kernels drop the pixels past the batch, and
+// tile kernels read the actual tile count from device memory (TileTab::d_count).
+struct TileTab {
+  DevBuf tab;        // int4 {img, y0, x0, 0}
+  DevBuf d_count;    // int[1]: tiles of the current batch (what the kernels loop / bound on in capacity mode)
+  int n = 0;         // tiles of the current batch
+  int cap = 0;       // capacity mode: table capacity == launch extent
+};
+
 struct Level {
   int n = 0;
   std::vector<int> h, w;
   std::vector<int64_t> off;      // pixel offset of image i
   int64_t total_px = 0;
   DevBuf d_tab;                   // int4 {off, h, w, 0} per image
-  // tile tables keyed by tile height (tile width is always 16): int4 {img, y0, x0, 0}
-  std::map<int, std::pair<DevBuf, int>> tiles;
+  // tile tables keyed by tile height (tile width is always 16)
+  std::map<int, TileTab> tiles;
+  // capacity mode
+  int cap_t16 = 0;                // > 0: capacity mode
+  int act_n = 0;
+  int64_t act_px = 0;
+  void* stage = nullptr;          // pinned host staging for the table uploads
+  size_t stage_bytes = 0;
 
+  Level() = default;
+  Level(const Level&) = delete;
+  Level& operator=(const Level&) = delete;
+  ~Level();
   void build(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st);
-  const int4* tile_table(int th, int* n_tiles, hipStream_t st);
+  void reserve(int cap_n, int64_t cap_px, int cap_tiles16, hipStream_t st);
+  void assign(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st);   // asynchronous on st (pinned staging)
+  bool capacity() const { return cap_t16 > 0; }
+  int64_t actual_px() const { return capacity() ? act_px : total_px; }
+  int actual_n() const { return capacity() ? act_n : n; }
+  // *n_launch: tiles to launch (capacity mode: the table capacity); *d_count: device count of real tiles (capacity mode) or nullptr
+  const int4* tile_table(int th, int* n_launch, const int** d_count, hipStream_t st);
   // for every pixel of this level the flat pixel index of its nearest-x2 source in `src` (same images at half size)
   std::map<const Level*, DevBuf> up2_maps;
   const int* up2_map(const Level* src, hipStream_t st);
-  long long count_tiles(int th) const;
+  long long count_tiles(int th) const;     // tiles of the current batch
+
+ private:
+  void fill_tiles(int th, TileTab& t, hipStream_t st, size_t* stage_off);
+  static int tile_cap(int cap_t16, int th) { return th >= 16 ? cap_t16 : cap_t16 * ((16 + th - 1) / th); }
 };
 
 // A view of `C` channels starting at `coff` inside pixel records of `cs` elements.

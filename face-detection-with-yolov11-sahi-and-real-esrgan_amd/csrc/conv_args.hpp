@@ -29,7 +29,14 @@ struct ConvArgs {
   const int* up_map;
   int up_c, up_cs;
   const void* zeros;   // 256 zero bytes in device memory (padding source of the LDS-DMA loader in conv_rows.hip)
+  const int* n_tiles_dev;   // capacity-mode levels (Level::reserve): the batch's tile count lives in device memory and the grid is
+                            // sized for the capacity — workgroups past n_tiles * n_nblk exit; nullptr: the grid is exact
 };
+
+// (logical workgroup id, number of live workgroups) for a tile kernel; live == 0: this workgroup has nothing to do
+__device__ __forceinline__ int live_workgroups(const ConvArgs& a) {
+  return a.n_tiles_dev ? __builtin_amdgcn_readfirstlane(*a.n_tiles_dev) * a.n_nblk : (int)gridDim.x;
+}
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   // blocks b and b+8 share an XCD (observed round-robin dispatch): give each XCD a contiguous run of logical ids.

@@ -149,7 +149,9 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
   const int wm = wave % WM, wn = wave / WM;
   const int p = lane & 31, hh = lane >> 5;
 
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int nwg = KS == 3 ? live_workgroups(a) : (int)gridDim.x;
+  if ((int)blockIdx.x >= nwg) return;                  // capacity-sized grid, smaller batch
+  const int L = xcd_remap(blockIdx.x, nwg);
   const int nblk = L % a.n_nblk, tile = L / a.n_nblk;
 
   int oy0 = 0, ox0 = 0, Ho = 1, Wo = 0, Hi = 0, Wi = 0;
@@ -548,7 +550,7 @@ template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int K
       if (KS == 1) {
         n_tiles = (int)((a.total_px + BLOCK_PX - 1) / BLOCK_PX);
       } else {
-        a.tiles = out_lvl->tile_table(G::TH, &n_tiles, st);
+        a.tiles = out_lvl->tile_table(G::TH, &n_tiles, &a.n_tiles_dev, st);
       }
       a.n_nblk = (a.ntiles32 * 32 + BLOCK_N - 1) / BLOCK_N;
       const int grid = n_tiles * a.n_nblk;
@@ -717,6 +719,7 @@ ConvArgs make_conv_args(const ConvOp& op) {
   a.in_tab = op.in.lvl->d_tab.as<int4>();
   a.out_tab = op.out.lvl->d_tab.as<int4>();
   a.tiles = nullptr;
+  a.n_tiles_dev = nullptr;
   a.total_px = op.out.lvl->total_px;
   a.in_cs = op.in.cs; a.in_coff = op.in.coff; a.cin = pc.cin; a.cin_pad = pc.cin_pad;
   a.out_cs = op.out.cs; a.out_coff = op.out.coff; a.cout = pc.cout;
@@ -754,6 +757,7 @@ ConvArgs make_conv_args(const ConvOp& op) {
   a.dbg = op.dbg;
   a.force_shape = op.force_shape;
   a.zeros = zero_block();
+  if (pc.k == 1) FFP_CHECK(!op.out.lvl->capacity(), FFP_ERR_ARG, "conv %s: 1x1 convs are not built for capacity-mode levels", pc.name.c_str());
   if (pc.k == 1) FFP_CHECK(op.in.lvl->total_px == op.out.lvl->total_px, FFP_ERR_ARG, "conv %s: 1x1 levels differ", pc.name.c_str());
   return a;
 }

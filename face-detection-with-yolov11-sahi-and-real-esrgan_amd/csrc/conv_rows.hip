@@ -58,7 +58,9 @@ __global__ void __launch_bounds__(256, NIW == 1 ? 2 : 1) conv_rows_kernel(const 
   const int p = lane & 31, hh = lane >> 5;
 
   // the channel blocks of one pixel tile are neighbours in the (XCD-contiguous) logical order: they share the input tile in L2
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int nwg = live_workgroups(a);
+  if ((int)blockIdx.x >= nwg) return;                  // capacity-sized grid, smaller batch
+  const int L = xcd_remap(blockIdx.x, nwg);
   const int nb = L % a.n_nblk, tile = L / a.n_nblk;
   const int nt0 = nb * NIW;                     // first 32-channel tile of this workgroup
   const int4 t = a.tiles[tile];
@@ -316,7 +318,7 @@ template <int NIW, int NST> struct RowsCfg {
   }
   static void launch(ConvArgs& a, Level* out_lvl, hipStream_t st) {
     int n_tiles = 0;
-    a.tiles = out_lvl->tile_table(16, &n_tiles, st);
+    a.tiles = out_lvl->tile_table(16, &n_tiles, &a.n_tiles_dev, st);
     if (n_tiles == 0) return;
     a.n_nblk = a.ntiles32 / NIW;
     hipLaunchKernelGGL((conv_rows_kernel<NIW, NST>), dim3(n_tiles * a.n_nblk), dim3(256), LDS, st, a);

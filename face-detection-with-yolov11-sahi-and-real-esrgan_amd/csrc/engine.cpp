@@ -56,6 +56,19 @@ Level* Plan::add_level(const std::vector<int>& hs, const std::vector<int>& ws, h
   return levels.back().get();
 }
 
+Level* Plan::add_level_capacity(int cap_n, int64_t cap_px, int cap_t16, hipStream_t st) {
+  levels.emplace_back(new Level());
+  levels.back()->reserve(cap_n, cap_px, cap_t16, st);
+  return levels.back().get();
+}
+
+double Plan::actual_conv_flops() const {
+  double f = 0;
+  for (const Step& s : steps)
+    if (s.is_conv) f += conv_flops_of(*s.conv->pc, s.conv->out.lvl->actual_px());
+  return f;
+}
+
 TView Plan::alloc(Level* l, int C, DType dt) {
   const size_t nb = (size_t)l->total_px * C * dsize(dt) + 256;   // slack: vector loads of the last record stay in bounds
   bufs.emplace_back(nb);
@@ -133,7 +146,7 @@ void Plan::execute(hipStream_t st, ConvProfile* prof) {
       if (s.is_conv) {
         const int slot = prof->open(st);
         s.run(st);
-        prof->close(slot, st, s.variant, s.flops, s.name);
+        prof->close(slot, st, s.variant, conv_flops_of(*s.conv->pc, s.conv->out.lvl->actual_px()), s.name);
       } else {
         s.run(st);
       }
@@ -154,6 +167,7 @@ void Plan::execute(hipStream_t st, ConvProfile* prof) {
         hipGraph_t g = nullptr;
         if (hipStreamEndCapture(st, &g) != hipSuccess || !ok || !g) {
           graph_ok = ++capture_failures < 3;          // an invalidated capture is retried on a later run, then given up
+          if (!graph_ok) fprintf(stderr, "libffp: hipGraph capture failed %d times, this plan keeps launching eagerly (ffp_*_graph_status reports -1)\n", capture_failures);
           if (g) (void)hipGraphDestroy(g);
           hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
           if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); }
@@ -161,6 +175,7 @@ void Plan::execute(hipStream_t st, ConvProfile* prof) {
         } else if (hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0) != hipSuccess) {
           graph_ok = false;
           gexec = nullptr;
+          fprintf(stderr, "libffp: hipGraphInstantiate failed, this plan keeps launching eagerly (ffp_*_graph_status reports -1)\n");
           (void)hipGraphDestroy(g);
           (void)hipGetLastError();
         } else {

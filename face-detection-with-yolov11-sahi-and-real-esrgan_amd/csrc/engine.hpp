@@ -53,6 +53,9 @@ struct Plan {
   ~Plan();
 
   Level* add_level(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st);
+  Level* add_level_capacity(int cap_n, int64_t cap_px, int cap_t16, hipStream_t st);     // Level::reserve
+  double actual_conv_flops() const;     // algorithmic FLOPs of the batch the levels currently describe (capacity-mode plans)
+  int graph_state() const { return gexec ? 1 : graph_ok ? 0 : -1; }    // 1 replaying a captured graph, 0 not captured yet, -1 capture failed: eager
   TView alloc(Level* l, int C, DType dt);
   void add_conv(const ConvOp& op);
   void add(std::function<void(hipStream_t)> f) { Step s; s.run = std::move(f); steps.push_back(std::move(s)); }

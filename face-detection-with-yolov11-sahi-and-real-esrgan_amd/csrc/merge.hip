@@ -204,9 +204,10 @@ __global__ void merge_emit_kernel(const float* __restrict__ rows, int stride, co
                                   const float4* __restrict__ kbox, const float* __restrict__ kscore, const int* __restrict__ ksrc,
                                   const int* __restrict__ d_k, int cap, float* __restrict__ out, int* __restrict__ out_src,
                                   int* __restrict__ out_n) {
+  // *out_n is the UNTRUNCATED count: a caller whose buffer is smaller sees n > cap and knows rows were dropped
   const int K = min(*d_k, cap);
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k == 0) *out_n = K;
+  if (k == 0) *out_n = *d_k;
   if (k >= K) return;
   const int src = order[ksrc[k]];
   const float* r = rows + (size_t)src * stride;
@@ -221,7 +222,7 @@ __global__ void merge_passthrough_kernel(const float* __restrict__ rows, int str
                                          float* __restrict__ out, int* __restrict__ out_src, int* __restrict__ out_n) {
   // fewer than two boxes: SAHI skips the post-process (docs sahi/predict.py:317)
   const int n = min(*d_n, cap);
-  if (threadIdx.x == 0) *out_n = n;
+  if (threadIdx.x == 0) *out_n = *d_n;
   for (int k = 0; k < n; ++k) {
     for (int c = threadIdx.x; c < stride; c += blockDim.x) out[(size_t)k * stride + c] = rows[(size_t)k * stride + c];
     if (threadIdx.x == 0 && out_src) out_src[k] = k;

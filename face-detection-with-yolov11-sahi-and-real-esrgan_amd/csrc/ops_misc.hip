@@ -267,7 +267,9 @@ __global__ void __launch_bounds__(256) conv3x3_c3_direct_kernel(const T* __restr
   if (gp >= total_out_px) return;
   const int im = find_img(out_tab, n_img, gp);
   const int4 to = out_tab[im], ti = in_tab[im];
-  const int lp = (int)(gp - to.x), oy = lp / to.z, ox = lp - oy * to.z;
+  const int lp = (int)(gp - to.x);
+  if (lp >= to.y * to.z) return;              // capacity-mode level: pixel past the current batch
+  const int oy = lp / to.z, ox = lp - oy * to.z;
   float acc[COUT];
 #pragma unroll
   for (int c = 0; c < COUT; ++c) acc[c] = 0.f;

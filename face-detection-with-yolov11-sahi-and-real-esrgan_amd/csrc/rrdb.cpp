@@ -50,13 +50,23 @@ const PackedConv* SrEngine::conv(const std::string& name) const {
   return &it->second;
 }
 
-void SrEngine::build_plan(SrPlan& P, const std::vector<int>& hs, const std::vector<int>& ws) {
-  const int n = (int)hs.size();
-  std::vector<int> h1(n), w1(n), h2(n), w2(n);
-  for (int i = 0; i < n; ++i) { h1[i] = hs[i] * 2; w1[i] = ws[i] * 2; h2[i] = hs[i] * 4; w2[i] = ws[i] * 4; }
-  P.Lb = P.add_level(hs, ws, st_);
-  P.L1 = P.add_level(h1, w1, st_);
-  P.L2 = P.add_level(h2, w2, st_);
+// capacity buckets: 64 * {1, 1.5, 2, 3, 4, 6, ...} 16x16 tiles at the body level (at most 1.5x the batch)
+static int capacity_bucket(long long t16) {
+  long long b = 64;
+  for (;;) {
+    if (t16 <= b) return (int)b;
+    if (t16 <= b + b / 2) return (int)(b + b / 2);
+    b *= 2;
+    FFP_CHECK(b < (1ll << 22), FFP_ERR_ARG, "enhance: batch of %lld tiles is too large", t16);
+  }
+}
+
+void SrEngine::build_plan(SrPlan& P, int cap_t16) {
+  // every image has at least one tile and a tile at most 256 pixels; x2 / x4 levels scale by 4 / 16
+  P.cap_t16 = cap_t16;
+  P.Lb = P.add_level_capacity(cap_t16, 256ll * cap_t16, cap_t16, st_);
+  P.L1 = P.add_level_capacity(cap_t16, 1024ll * cap_t16, 4 * cap_t16, st_);
+  P.L2 = P.add_level_capacity(cap_t16, 4096ll * cap_t16, 16 * cap_t16, st_);
   const DType T = dt_;
   const int cin = conv("conv_first")->cin;     // padded to the vector width
   P.input = P.alloc(P.Lb, cin, T);
@@ -104,9 +114,39 @@ void SrEngine::build_plan(SrPlan& P, const std::vector<int>& hs, const std::vect
   cv("conv_hr", u2, hr, ACT_LRELU);
   P.out = P.alloc(P.L2, 4, F32);
   cv("conv_last", hr, P.out.slice(0, 3), ACT_NONE);
+  const size_t n = (size_t)cap_t16;
   P.d_srcs.alloc(sizeof(SrSrc) * n);
   P.d_dsts.alloc(sizeof(SrDst) * n);
   P.d_core_off.alloc(sizeof(long long) * (n + 1));
+  P.stage_bytes = (sizeof(SrSrc) + sizeof(SrDst) + sizeof(long long)) * (n + 1);
+  FFP_HIP(hipHostMalloc(&P.stage, P.stage_bytes, hipHostMallocDefault));
+}
+
+SrPlan::~SrPlan() {
+  if (stage) (void)hipHostFree(stage);
+}
+
+SrPlan& SrEngine::plan_for(long long t16) {
+  // smallest resident plan that holds the batch; else a new one at the next capacity bucket (least recently used one evicted)
+  SrPlan* best = nullptr;
+  for (auto& kv : plans_)
+    if (kv.first >= t16 && (!best || kv.first < best->cap_t16)) best = kv.second.get();
+  if (!best) {
+    const int cap = capacity_bucket(t16);
+    if (plans_.size() >= 4) {
+      auto victim = plans_.begin();
+      for (auto it = plans_.begin(); it != plans_.end(); ++it)
+        if (it->second->last_use < victim->second->last_use) victim = it;
+      plans_.erase(victim);
+    }
+    std::unique_ptr<SrPlan> p(new SrPlan());
+    build_plan(*p, cap);
+    ++plans_built;
+    best = p.get();
+    plans_.emplace(cap, std::move(p));
+  }
+  best->last_use = ++use_clock_;
+  return *best;
 }
 
 void SrEngine::wait_done() {
@@ -160,33 +200,39 @@ void SrEngine::enhance_dev(const uint8_t* d_in, uint8_t* d_out, const std::vecto
       }
   }
   const int n = (int)tiles.size();
-  std::vector<int> key, hs(n), ws(n);
-  for (int i = 0; i < n; ++i) { hs[i] = tiles[i].h / shuf; ws[i] = tiles[i].w / shuf; key.push_back(hs[i]); key.push_back(ws[i]); }
-  auto it = plans_.find(key);
-  if (it == plans_.end()) {
-    if (plans_.size() >= 8) plans_.clear();
-    std::unique_ptr<SrPlan> p(new SrPlan());
-    build_plan(*p, hs, ws);
-    it = plans_.emplace(key, std::move(p)).first;
+  std::vector<int> hs(n), ws(n), h1(n), w1(n), h2(n), w2(n);
+  long long t16 = 0;
+  for (int i = 0; i < n; ++i) {
+    hs[i] = tiles[i].h / shuf; ws[i] = tiles[i].w / shuf;
+    h1[i] = hs[i] * 2; w1[i] = ws[i] * 2; h2[i] = hs[i] * 4; w2[i] = ws[i] * 4;
+    t16 += (long long)((hs[i] + 15) / 16) * ((ws[i] + 15) / 16);
   }
-  SrPlan& P = *it->second;
-  std::vector<SrSrc> srcs(n);
-  std::vector<SrDst> dsts(n);
-  std::vector<long long> coff(n + 1);
+  // The plan depends on a CAPACITY, not on the sizes: a new multiset of crop sizes (every frame of a real stream) costs table
+  // uploads only — no allocation, no tuning, no graph capture (the reference enhances arbitrary crops back to back,
+  // utils/enhancer.py:344-391).
+  SrPlan& P = plan_for(t16);
+  P.Lb->assign(hs, ws, st_);
+  P.L1->assign(h1, w1, st_);
+  P.L2->assign(h2, w2, st_);
+  const int cap = P.cap_t16;
+  SrSrc* srcs = reinterpret_cast<SrSrc*>(P.stage);
+  SrDst* dsts = reinterpret_cast<SrDst*>(srcs + cap);
+  long long* coff = reinterpret_cast<long long*>(dsts + cap);
   long long tot = 0;
   for (int i = 0; i < n; ++i) { srcs[i] = tiles[i].src; dsts[i] = tiles[i].dst; coff[i] = tot; tot += (long long)dsts[i].cw * dsts[i].ch; }
-  coff[n] = tot;
-  FFP_HIP(hipMemcpyAsync(P.d_srcs.p, srcs.data(), sizeof(SrSrc) * n, hipMemcpyHostToDevice, st_));
-  FFP_HIP(hipMemcpyAsync(P.d_dsts.p, dsts.data(), sizeof(SrDst) * n, hipMemcpyHostToDevice, st_));
-  FFP_HIP(hipMemcpyAsync(P.d_core_off.p, coff.data(), sizeof(long long) * (n + 1), hipMemcpyHostToDevice, st_));
-  FFP_HIP(hipStreamSynchronize(st_));
+  for (int i = n; i < cap; ++i) { dsts[i] = SrDst{}; coff[i] = tot; }       // padding entries: empty cores behind the last real one
+  coff[cap] = tot;
+  FFP_HIP(hipMemcpyAsync(P.d_srcs.p, srcs, sizeof(SrSrc) * n, hipMemcpyHostToDevice, st_));
+  FFP_HIP(hipMemcpyAsync(P.d_dsts.p, dsts, sizeof(SrDst) * cap, hipMemcpyHostToDevice, st_));
+  FFP_HIP(hipMemcpyAsync(P.d_core_off.p, coff, sizeof(long long) * (cap + 1), hipMemcpyHostToDevice, st_));
   FFP_HIP(hipEventRecord(ev_[0], st_));
   launch_sr_pre(d_in, P.d_srcs.as<SrSrc>(), P.input, shuf, st_);
   if (prof.enabled) prof.begin();
   P.execute(st_, &prof);
-  launch_sr_post(P.out, P.d_dsts.as<SrDst>(), P.d_core_off.as<long long>(), tot, d_out, st_);
+  launch_sr_post(P.out, P.d_dsts.as<SrDst>(), P.d_core_off.as<long long>(), P.L2->total_px, d_out, st_);
   FFP_HIP(hipEventRecord(ev_[1], st_));
-  last_conv_flops = P.conv_flops;
+  last_conv_flops = P.actual_conv_flops();
+  last_graph = P.gexec != nullptr;
   last_conv_launches = P.conv_launches;
   pending_ = true;
   if (wait) wait_done();

@@ -34,7 +34,9 @@ __global__ void sr_pre_kernel(const uint8_t* __restrict__ base, const SrSrc* __r
   const int im = find_img(tab, n_img, gp);
   const int4 t = tab[im];
   const SrSrc s = srcs[im];
-  const int lp = (int)(gp - t.x), y = lp / t.z, x = lp - y * t.z;
+  const int lp = (int)(gp - t.x);
+  if (lp >= t.y * t.z) return;                // capacity-mode level: pixel past the current batch
+  const int y = lp / t.z, x = lp - y * t.z;
   T* op = out + (size_t)gp * CPAD;
   const uint8_t* img = base + s.src_off;
 #pragma unroll
@@ -65,7 +67,9 @@ __global__ void sr_post_kernel(const float* __restrict__ net_out, int cs, const 
   const int im = lo;
   const SrDst d = dsts[im];
   const int4 t = tab[im];
-  const int lp = (int)(g - core_off[im]), y = lp / d.cw, x = lp - y * d.cw;
+  const int lp = (int)(g - core_off[im]);
+  if (lp >= d.cw * d.ch) return;              // padding entry (capacity-mode batch) or empty core
+  const int y = lp / d.cw, x = lp - y * d.cw;
   const float* p = net_out + ((size_t)t.x + (size_t)(d.ty + y) * t.z + (d.tx + x)) * cs;
   uint8_t* o = base + d.dst_off + (size_t)(d.oy + y) * d.dst_stride + (size_t)(d.ox + x) * 3;
 #pragma unroll

@@ -25,12 +25,19 @@ void launch_sr_post(const TView& net_out, const SrDst* d_dsts, const long long* 
 void launch_crop_gather(const uint8_t* d_frame, int W, const int4* d_boxes, const long long* d_offs, int n, uint8_t* d_out,
                         hipStream_t st);
 
+// A plan is laid out for a CAPACITY (16x16 tiles at the body level), not for a list of image sizes: its levels are in
+// capacity mode (Level::reserve / assign), so one allocated, tuned and graph-captured plan serves every batch that fits.
 struct SrPlan : Plan {
   Level* Lb = nullptr;     // body level (input res, or half res for x2)
   Level* L1 = nullptr;     // x2 of body
   Level* L2 = nullptr;     // x4 of body
   TView input, out;
   DevBuf d_srcs, d_dsts, d_core_off;
+  int cap_t16 = 0;
+  void* stage = nullptr;   // pinned staging of the per-batch tile descriptors
+  size_t stage_bytes = 0;
+  unsigned long long last_use = 0;
+  ~SrPlan();
 };
 
 struct SrImage {           // one image of a batch: offsets are relative to the in/out base allocations
@@ -52,17 +59,22 @@ class SrEngine {
   void wait_done();
 
   DevBuf scratch_in, scratch_out, scratch_boxes, scratch_offs;
+  HostPinned crop_stage;
   ConvProfile prof;
   float last_ms = 0.f;
   double last_conv_flops = 0;
   int last_conv_launches = 0;
+  bool last_graph = false;      // the last call replayed a captured hipGraph (false: eager launches)
+  int plans_built = 0;          // plans laid out so far (a steady stream of varying crop sizes must not grow this)
 
  private:
   struct TileDesc { SrSrc src; SrDst dst; int h, w; };
-  void build_plan(SrPlan& P, const std::vector<int>& hs, const std::vector<int>& ws);
+  void build_plan(SrPlan& P, int cap_t16);
+  SrPlan& plan_for(long long t16);
+  unsigned long long use_clock_ = 0;
   const PackedConv* conv(const std::string& name) const;
   std::map<std::string, PackedConv> convs_;
-  std::map<std::vector<int>, std::unique_ptr<SrPlan>> plans_;
+  std::map<int, std::unique_ptr<SrPlan>> plans_;      // keyed by capacity
   int scale_ = 4, num_block_ = 23, device_ = 0;
   DType dt_ = F16;
   hipStream_t st_ = nullptr;

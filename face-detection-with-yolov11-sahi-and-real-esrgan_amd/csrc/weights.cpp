@@ -33,7 +33,9 @@ void WeightFile::parse(const void* bytes, size_t n) {
     HostTensor ht;
     for (int d = 0; d < nd; ++d) ht.dims.push_back((int)rd<uint32_t>(p, end));
     uint64_t off = rd<uint64_t>(p, end), nb = rd<uint64_t>(p, end);
-    FFP_CHECK(data_off + off + nb <= n && nb == ht.numel() * 4, FFP_ERR_WEIGHTS, "FFPW: tensor %s out of bounds", name.c_str());
+    // no sum of file-provided 64-bit fields: each is checked against what is left, so nothing can wrap
+    FFP_CHECK(off <= n - data_off && nb <= n - data_off - off && nb / 4 == ht.numel() && nb % 4 == 0, FFP_ERR_WEIGHTS,
+              "FFPW: tensor %s out of bounds", name.c_str());
     ht.data = reinterpret_cast<const float*>(base + data_off + off);
     t[name] = ht;
   }

@@ -341,6 +341,7 @@ DetPlan* DetEngine::prepare(const uint8_t* d_frame, int H, int W, int chan_order
   FFP_HIP(hipEventRecord(ev_[2], st_));
   last_conv_flops = P->conv_flops;
   last_conv_launches = P->conv_launches;
+  last_graph_state = P->graph_state();
   return P;
 }
 

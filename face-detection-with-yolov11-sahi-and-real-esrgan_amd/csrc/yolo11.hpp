@@ -51,6 +51,7 @@ class DetEngine {
   float last_ms[5] = {0, 0, 0, 0, 0};
   double last_conv_flops = 0;
   int last_conv_launches = 0;
+  int last_graph_state = 0;     // Plan::graph_state() of the plan the last call ran
   hipEvent_t ev_[6];
 
  private:

@@ -4,10 +4,12 @@
 
 Multi-GPU: a step processes a batch of B frames stacked into one tall "super-frame" (frames cannot interact in the
 merge because their boxes never overlap). The work items — every slice of every frame, each followed by that
-frame's full-frame pass, in SAHI's own order (docs sahi/predict.py:270-314) — are split contiguously over the ranks,
-each rank writes fixed-cap detections [items_per_rank][max_det][stride] and the ranks exchange them with ONE
-all-gather (1.5 MB per 61 items): the only data-path collective. Frame f is then merged and its crops enhanced by rank
-f % world.
+frame's full-frame pass, in SAHI's own order (docs sahi/predict.py:270-314) — are split into contiguous, cost-balanced
+blocks over the ranks (`partition`: cost = pixels entering the network), each rank writes fixed-cap detections
+[slots_per_rank][max_det][stride] and, when a frame's items are spread over ranks (the north_star's split: the slices of
+ONE image across the GPUs), the ranks exchange them with ONE all-gather (1.5 MB per 61 items): the only data-path
+collective; every rank then runs the identical deterministic merge. When every frame lives on one rank (weak scaling with
+whole frames per rank) no rank needs another's boxes and the exchange is skipped. SR crops are placed by LPT (`lpt_assign`).
 """
 from __future__ import annotations
 
@@ -36,7 +38,9 @@ class PipeConfig:
     perform_standard_pred: bool = True
     chan_order: int = _lib.CHAN_AS_BGR
     sr_crops: int = 32            # crops enhanced per frame (0: detection only)
-    merge_cap: int = 4096
+    sr_tile: int = 400            # FaceEnhancer's tile / tile_pad (utils/enhancer.py:21,135-142): crops larger than the tile are tiled
+    sr_tile_pad: int = 10
+    merge_cap: int = 4096         # rows of the merged-detections buffer; merge_frame raises when a frame yields more
 
 
 def frame_items(H: int, W: int, cfg: PipeConfig, n_frames: int = 1) -> np.ndarray:
@@ -53,10 +57,128 @@ def frame_items(H: int, W: int, cfg: PipeConfig, n_frames: int = 1) -> np.ndarra
     return np.concatenate(items, 0).astype(np.int32)
 
 
+def item_costs(items: np.ndarray, imgsz: int) -> np.ndarray:
+    """Relative cost of each work item = pixels entering the network (LetterBox geometry of the item at `imgsz`;
+    imgsz <= 0: native). A 4K full-frame pass at 512 is 288x512 = 0.56 of a 512x512 slice."""
+    out = np.zeros(len(items), np.float64)
+    cache = {}
+    for k, (x0, y0, x1, y1) in enumerate(items):
+        h, w = int(y1 - y0), int(x1 - x0)
+        if (h, w) not in cache:
+            sz = imgsz if imgsz > 0 else (max(h, w) + 31) // 32 * 32
+            nw, nh, t, b, l, r = _lib.letterbox_geometry(h, w, sz)
+            cache[(h, w)] = float((nh + t + b) * (nw + l + r))
+        out[k] = cache[(h, w)]
+    return out
+
+
+def partition(costs: Sequence[float], world: int):
+    """Contiguous partition of the item list into `world` blocks minimising the heaviest block (contiguous by
+    row-major index so that the gathered buffer is in SAHI's own order). Returns [(lo, hi)] per rank; a rank may be empty
+    only when there are fewer items than ranks."""
+    c = np.asarray(costs, np.float64)
+    n = len(c)
+    if world <= 1 or n == 0:
+        return [(0, n)] + [(n, n)] * (max(world, 1) - 1)
+
+    def blocks(limit):
+        out, lo, acc = [], 0, 0.0
+        for i in range(n):
+            if acc + c[i] > limit and i > lo:
+                out.append((lo, i))
+                lo, acc = i, 0.0
+            acc += c[i]
+        out.append((lo, n))
+        return out
+
+    lo_t, hi_t = float(c.max()), float(c.sum())
+    for _ in range(60):
+        mid = 0.5 * (lo_t + hi_t)
+        if len(blocks(mid)) <= world:
+            hi_t = mid
+        else:
+            lo_t = mid
+    b = blocks(hi_t * (1 + 1e-12))
+    while len(b) < min(world, n):                       # fewer blocks than ranks: split the heaviest splittable block
+        k = max((i for i in range(len(b)) if b[i][1] - b[i][0] > 1), key=lambda i: c[b[i][0]:b[i][1]].sum())
+        lo, hi = b[k]
+        cs = np.cumsum(c[lo:hi])
+        m = lo + 1 + int(np.argmin(np.abs(cs[:-1] - cs[-1] / 2)))
+        b[k:k + 1] = [(lo, m), (m, hi)]
+    return b + [(n, n)] * (world - len(b))
+
+
 def shard(n_items: int, rank: int, world: int):
-    per = (n_items + world - 1) // world
-    lo = min(rank * per, n_items)
-    return lo, min(lo + per, n_items), per
+    """Equal-cost items: (lo, hi, slots per rank) of rank's contiguous share."""
+    b = partition(np.ones(n_items), world)
+    return b[rank][0], b[rank][1], max(h - l for l, h in b)
+
+
+class Layout:
+    """Where every work item of a super-frame lives: global order `items`, per-rank contiguous blocks `bounds`, and the slot
+    of an item in the fixed-cap exchange buffer (rank r's k-th item sits at r * per + k; unused slots keep count 0, so any
+    slot range is still in SAHI's order)."""
+
+    def __init__(self, items: np.ndarray, n_frames: int, world: int, costs: np.ndarray):
+        self.items, self.n_frames, self.world = items, n_frames, world
+        self.ipf = len(items) // n_frames
+        self.bounds = partition(costs, world)
+        self.per = max(1, max(h - l for l, h in self.bounds))
+
+    def rank_of(self, i: int) -> int:
+        for r, (lo, hi) in enumerate(self.bounds):
+            if lo <= i < hi:
+                return r
+        raise IndexError(i)
+
+    def slot(self, i: int) -> int:
+        r = self.rank_of(i)
+        return r * self.per + (i - self.bounds[r][0])
+
+    def owner(self, f: int) -> int:
+        """The rank holding ALL items of frame f, or -1 when the frame is spread over ranks."""
+        a, b = f * self.ipf, (f + 1) * self.ipf
+        r = self.rank_of(a)
+        return r if self.bounds[r][1] >= b else -1
+
+    @property
+    def aligned(self) -> bool:
+        """Every frame lives on one rank: no detection of one rank is needed by another, the exchange can be skipped."""
+        return all(self.owner(f) >= 0 for f in range(self.n_frames))
+
+    def frame_slots(self, f: int, gathered: bool, rank: int = 0):
+        """(first slot, slot count) of frame f in the gathered buffer, or in rank's local buffer when nothing was exchanged."""
+        a, b = f * self.ipf, (f + 1) * self.ipf
+        if gathered:
+            s0, s1 = self.slot(a), self.slot(b - 1)
+            return s0, s1 - s0 + 1
+        lo, hi = self.bounds[rank]
+        assert lo <= a and b <= hi, "frame is not local to this rank"
+        return a - lo, b - a
+
+    def rows_needed(self, rank: int, H: int):
+        """Row range of the super-frame rank must have resident: the rows its items read, the frames it owns (merge + crops) and
+        every frame that is spread over ranks (its merge is replicated and its crops are placed on all ranks by LPT)."""
+        lo, hi = self.bounds[rank]
+        ys = [(int(self.items[i][1]), int(self.items[i][3])) for i in range(lo, hi)]
+        ys += [(f * H, (f + 1) * H) for f in range(self.n_frames) if self.owner(f) in (rank, -1)]
+        if not ys:
+            return 0, 0
+        return min(y[0] for y in ys), max(y[1] for y in ys)
+
+
+def lpt_assign(weights: Sequence[float], world: int) -> np.ndarray:
+    """Longest-processing-time placement (SR crops): heaviest first, each to the least-loaded rank (ties: lowest
+    rank, lower index first). Deterministic, so every rank derives the same placement from the same merged boxes."""
+    w = np.asarray(weights, np.float64)
+    order = sorted(range(len(w)), key=lambda i: (-w[i], i))
+    load = np.zeros(max(world, 1))
+    out = np.zeros(len(w), np.int32)
+    for i in order:
+        r = int(np.argmin(load))
+        out[i] = r
+        load[r] += w[i]
+    return out
 
 
 def crop_boxes_for_sr(rows: np.ndarray, H: int, W: int, n: int, sizes: Sequence[int], seed: int) -> np.ndarray:
@@ -117,6 +239,7 @@ class FramePipeline:
         self.sr = _lib.Enhancer(sr_weights, 4, 23, device=device, half=sr_half) if (cfg.sr_crops > 0 and sr_weights is not None) else None
         self.stride = self.det.stride
         self._bufs = {}
+        self._layouts = {}
 
     def _buf(self, name, shape, dtype):
         t = self._bufs.get(name)
@@ -126,25 +249,70 @@ class FramePipeline:
             self._bufs[name] = t
         return t
 
-    def detect(self, d_frame, H: int, W: int, n_frames: int = 1):
-        """d_frame: uint8 cuda tensor (n_frames*H, W, 3). Returns (gathered dets [n_items_pad][max_det][stride], counts, items)."""
+    def _bytes(self, name, nbytes: int):
+        """Grow-only uint8 scratch (crop outputs change size every frame: no per-frame allocation or fill)."""
+        t = self._bufs.get(name)
+        if t is None or t.numel() < nbytes:
+            t = self.torch.empty((max(int(nbytes * 1.5), 1 << 20),), dtype=self.torch.uint8, device=self.dev)
+            self.torch.cuda.synchronize(self.dev)
+            self._bufs[name] = t
+        return t[:max(nbytes, 1)]
+
+    @staticmethod
+    def sr_out_bytes(boxes: np.ndarray, H: int, W: int, scale: int = 4) -> int:
+        """Bytes ffp_sr_enhance_crops_* packs for these boxes (int box clamped to the frame, 16-byte aligned entries)."""
+        tot = 0
+        for b in boxes:
+            w = min(W, int(b[2])) - max(0, int(b[0]))
+            h = min(H, int(b[3])) - max(0, int(b[1]))
+            if w > 0 and h > 0:
+                tot += (h * scale * w * scale * 3 + 15) // 16 * 16
+        return tot
+
+    def merged_count(self, outn) -> int:
+        """Host value of merge_frame's count; raises when the frame produced more merged detections than merge_cap rows."""
+        n = int(outn.item())
+        if n > self.cfg.merge_cap:
+            raise _lib.FfpError(1, f"{n} merged detections exceed merge_cap={self.cfg.merge_cap}: raise PipeConfig.merge_cap")
+        return n
+
+    def layout(self, H: int, W: int, n_frames: int = 1) -> Layout:
+        key = (H, W, n_frames)
+        L = self._layouts.get(key)
+        if L is None:
+            items = frame_items(H, W, self.cfg, n_frames)
+            L = Layout(items, n_frames, self.world, item_costs(items, self.cfg.imgsz))
+            self._layouts[key] = L
+        return L
+
+    def detect(self, d_frame, H: int, W: int, n_frames: int = 1, exchange: str = "auto"):
+        """d_frame: uint8 cuda tensor (n_frames*H, W, 3); only layout.rows_needed(rank) have to be valid.
+        Returns (dets [slots][max_det][stride], counts [slots], layout, gathered). exchange: "auto" skips the all-gather when every
+        frame's items live on one rank (weak scaling with whole frames per rank), "always" / "never" force it."""
         torch, cfg = self.torch, self.cfg
-        items = frame_items(H, W, cfg, n_frames)
-        n_items = items.shape[0]
-        lo, hi, per = shard(n_items, self.rank, self.world)
-        local = self._buf("local_dets", (per, cfg.max_det, self.stride), torch.float32)
-        lcount = self._buf("local_counts", (per,), torch.int32)   # entries past this rank's share stay 0
+        L = self.layout(H, W, n_frames)
+        lo, hi = L.bounds[self.rank]
+        local = self._buf("local_dets", (L.per, cfg.max_det, self.stride), torch.float32)
+        lcount = self._buf("local_counts", (L.per,), torch.int32)   # entries past this rank's share stay 0
         if hi > lo:
-            t = np.ascontiguousarray(items[lo:hi])
+            t = np.ascontiguousarray(L.items[lo:hi])
             _lib._check(_lib.lib().ffp_det_infer_tiles_dev(self.det.handle, d_frame.data_ptr(), H * n_frames, W, cfg.chan_order, _lib._ip(t),
                                                            hi - lo, cfg.imgsz, cfg.conf, cfg.iou, cfg.max_det, 0, local.data_ptr(),
                                                            lcount.data_ptr()))
             self._truncate_shift(local, lcount, hi - lo, H * n_frames, W)
-        if self.world > 1:
+        if hi - lo < L.per:
+            lcount[hi - lo:].zero_()
+            torch.cuda.synchronize(self.dev)
+        need = self.world > 1 and (exchange == "always" or (exchange == "auto" and not L.aligned))
+        if need:
             g, gc = exchange_detections(local, lcount, self.world)
             torch.cuda.synchronize(self.dev)       # libffp's stream must see the gathered boxes
-            return g, gc, items
-        return local, lcount, items
+            return g, gc, L, True
+        return local, lcount, L, False
+
+    def merge_frame_of(self, dets, counts, L: Layout, f: int, gathered: bool):
+        s0, ns = L.frame_slots(f, gathered, self.rank)
+        return self.merge_frame(dets, counts, s0, ns)
 
     def _truncate_shift(self, dets, counts, n, H, W):
         # wrapper + SAHI shift semantics on the device (utils/yolo_wrapper.py:137-162, docs sahi/prediction.py:94-120)
@@ -165,29 +333,19 @@ class FramePipeline:
     def enhance_crops(self, d_frame_bgr, H: int, W: int, boxes: np.ndarray, wait: bool = True, slot: int = 0):
         """Real-ESRGAN x4 on crops of a resident BGR frame. Returns (uint8 cuda tensor with all outputs, offsets).
         wait=False enqueues on the enhancer's stream and returns; call wait_sr() before reading the tensor."""
-        torch = self.torch
-        n = boxes.shape[0]
-        tot = int(sum(((int(b[3] - b[1]) * 4) * (int(b[2] - b[0]) * 4) * 3 + 15) // 16 * 16 for b in boxes))
-        out = self._buf(f"sr_out{slot}", (tot,), torch.uint8)
-        offs = np.zeros(n + 1, np.int64)
-        b = np.ascontiguousarray(boxes, np.int32)
-        fn = _lib.lib().ffp_sr_enhance_crops_dev if wait else _lib.lib().ffp_sr_enhance_crops_dev_async
-        _lib._check(fn(self.sr.handle, d_frame_bgr.data_ptr(), H, W, _lib._ip(b), n, out.data_ptr(), tot,
-                                                        offs.ctypes.data_as(C.POINTER(C.c_int64))))
+        tot = self.sr_out_bytes(boxes, H, W, self.sr.scale)
+        out = self._bytes(f"sr_out{slot}", tot)
+        offs = self.sr.enhance_crops_dev([d_frame_bgr.data_ptr()], H, W, boxes, out.data_ptr(), tot, None, self.cfg.sr_tile, self.cfg.sr_tile_pad, wait)
         return out, offs
 
     def enhance_crops_multi(self, d_frames, H: int, W: int, boxes_per_frame, slot: int = 0):
         """Crops of several resident frames as ONE ragged SR batch (async; wait_sr() before reading)."""
-        torch = self.torch
         boxes = np.ascontiguousarray(np.concatenate(boxes_per_frame, 0), np.int32)
         fidx = np.ascontiguousarray(np.concatenate([np.full(len(b), i, np.int32) for i, b in enumerate(boxes_per_frame)]))
-        n = boxes.shape[0]
-        tot = int(sum(((int(b[3] - b[1]) * 4) * (int(b[2] - b[0]) * 4) * 3 + 15) // 16 * 16 for b in boxes))
-        out = self._buf(f"sr_out{slot}", (tot,), torch.uint8)
-        offs = np.zeros(n + 1, np.int64)
-        ptrs = (C.c_void_p * len(d_frames))(*[t.data_ptr() for t in d_frames])
-        _lib._check(_lib.lib().ffp_sr_enhance_crops_multi_dev_async(self.sr.handle, len(d_frames), ptrs, _lib._ip(fidx), H, W, _lib._ip(boxes), n,
-                                                                    out.data_ptr(), tot, offs.ctypes.data_as(C.POINTER(C.c_int64))))
+        tot = self.sr_out_bytes(boxes, H, W, self.sr.scale)
+        out = self._bytes(f"sr_out{slot}", tot)
+        offs = self.sr.enhance_crops_dev([t.data_ptr() for t in d_frames], H, W, boxes, out.data_ptr(), tot, fidx, self.cfg.sr_tile,
+                                         self.cfg.sr_tile_pad, wait=False)
         return out, offs
 
     def enhance_frame(self, d_frame_bgr, H: int, W: int, enhancer=None, tile: int = 400, tile_pad: int = 10, pre_pad: int = 0):
@@ -206,8 +364,8 @@ class FramePipeline:
         Returns (enhanced frame, merged rows, count) — all resident."""
         enh = self.enhance_frame(d_frame_bgr, H, W, enhancer, tile, tile_pad)
         He, We = int(enh.shape[0]), int(enh.shape[1])
-        dets, counts, items = self.detect(enh, He, We, 1)
-        rows, n = self.merge_frame(dets, counts, 0, items.shape[0])
+        dets, counts, L, gathered = self.detect(enh, He, We, 1)
+        rows, n = self.merge_frame_of(dets, counts, L, 0, gathered)
         return enh, rows, n
 
     def wait_sr(self):

@@ -146,7 +146,9 @@ int ffp_det_stage_dev(ffp_det* d, const uint8_t* d_frame_hwc, int H, int W, int 
                       int32_t* d_local_counts, int32_t* out_n_local, int32_t* out_n_total);
 
 /* Merge of fixed-cap per-slice detections already on the device: d_dets [n_slices][max_det][stride] (full-frame,
- * truncated+shifted), d_counts[n_slices].  d_out [cap][stride], d_out_n[1] device pointers. */
+ * truncated+shifted), d_counts[n_slices].  d_out [cap][stride], d_out_n[1] device pointers.
+ * *d_out_n receives the UNTRUNCATED number of merged detections; when it exceeds cap only the first cap rows were
+ * written and the caller must treat the result as overflowed (ffp_sliced_predict returns FFP_ERR_ARG in that case). */
 int ffp_merge_dev(ffp_det* d, const float* d_dets, const int32_t* d_counts, int n_slices, int max_det, int type,
                   int metric, double thr, int class_agnostic, float* d_out, int cap, int32_t* d_out_n);
 
@@ -175,22 +177,33 @@ int ffp_sr_enhance_batch(ffp_sr* s, int n, const uint8_t* const* imgs, const int
                          int tile_pad, int pre_pad, uint8_t* const* outs);
 
 /* Crops gathered on the device from a resident frame (utils/visualization.py:185-223 crop semantics: int box,
- * clamped to the frame), enhanced, outputs packed back to back in d_out (device), offsets in out_offsets (host,
- * n+1 entries, bytes). frame is BGR. boxes_xyxy: host int32 [n][4]. */
-int ffp_sr_enhance_crops_dev(ffp_sr* s, const uint8_t* d_frame_bgr, int H, int W, const int32_t* boxes_xyxy, int n,
-                             uint8_t* d_out, size_t out_cap, int64_t* out_offsets);
+ * clamped to the frame, an empty crop is skipped), each enhanced like FaceEnhancer.enhance_image does
+ * (utils/enhancer.py:189-235 -> RealESRGANer.enhance with the enhancer's tile setting: tile 400 / tile_pad 10 at
+ * utils/enhancer.py:21,135-142; tile <= 0: one pass per crop), outputs packed back to back in d_out (device), byte
+ * offsets in out_offsets (host, n+1 entries; a skipped crop has out_offsets[i+1] == out_offsets[i]).
+ * frame is BGR. boxes_xyxy: host int32 [n][4]. */
+int ffp_sr_enhance_crops_dev(ffp_sr* s, const uint8_t* d_frame_bgr, int H, int W, const int32_t* boxes_xyxy, int n, int tile,
+                             int tile_pad, uint8_t* d_out, size_t out_cap, int64_t* out_offsets);
 
 /* Same, but returns once the work is enqueued on the enhancer's own HIP stream; ffp_sr_wait() blocks until d_out is
  * complete. Lets a caller overlap frame i's super-resolution with frame i+1's detection (the detector handle has its
  * own stream). d_frame and d_out must stay untouched until ffp_sr_wait (or the next call on the handle) returns. */
-int ffp_sr_enhance_crops_dev_async(ffp_sr* s, const uint8_t* d_frame_bgr, int H, int W, const int32_t* boxes_xyxy, int n,
-                                   uint8_t* d_out, size_t out_cap, int64_t* out_offsets);
+int ffp_sr_enhance_crops_dev_async(ffp_sr* s, const uint8_t* d_frame_bgr, int H, int W, const int32_t* boxes_xyxy, int n, int tile,
+                                   int tile_pad, uint8_t* d_out, size_t out_cap, int64_t* out_offsets);
 int ffp_sr_wait(ffp_sr* s);
 /* Crops of SEVERAL resident frames (all H x W) as one ragged batch: frame_of_box[i] selects d_frames[...] for box i
  * (boxes of one frame must be contiguous). More pixels per launch = better use of the chip when a frame yields few crops. */
 int ffp_sr_enhance_crops_multi_dev_async(ffp_sr* s, int n_frames, const uint8_t* const* d_frames, const int32_t* frame_of_box,
-                                         int H, int W, const int32_t* boxes_xyxy, int n, uint8_t* d_out, size_t out_cap,
-                                         int64_t* out_offsets);
+                                         int H, int W, const int32_t* boxes_xyxy, int n, int tile, int tile_pad, uint8_t* d_out,
+                                         size_t out_cap, int64_t* out_offsets);
+
+/* Engine state for tests and monitoring. The enhancer lays its network out for a CAPACITY (pixels / tiles), not for a list
+ * of crop sizes: out_plans_built counts the layouts built so far (a stream of frames with ever-changing crop sizes must
+ * not grow it), out_last_graph tells whether the last call replayed a captured hipGraph (1) or launched eagerly (0). */
+int ffp_sr_plan_state(ffp_sr* s, int32_t* out_plans_built, int32_t* out_last_graph);
+/* hipGraph state of the plan the detector's last call ran: 1 replayed a captured graph, 0 not captured yet (first runs of a
+ * plan are eager), -1 capture failed and the plan keeps launching eagerly (also reported once on stderr). */
+int ffp_det_graph_status(ffp_det* d, int32_t* out_state);
 
 /* ---------------------------------------------------------------------------------------------------------
  * single-operator entry points (layer-wise parity tests; host NHWC fp32 in/out, computed on `device` in `precision`)

@@ -35,17 +35,18 @@ def _worker(rank, world, port, n_frames, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        cfg = pipeline.PipeConfig()
-        items = pipeline.frame_items(540, 960, pipeline.PipeConfig(slice_h=256, slice_w=256), n_frames)
-        lo, hi, per = pipeline.shard(len(items), rank, world)
-        local = torch.zeros((per, MAX_DET, STRIDE))
-        counts = torch.zeros((per,), dtype=torch.int32)
+        cfg = pipeline.PipeConfig(slice_h=256, slice_w=256, imgsz=256)
+        items = pipeline.frame_items(540, 960, cfg, n_frames)
+        L = pipeline.Layout(items, n_frames, world, pipeline.item_costs(items, cfg.imgsz))
+        lo, hi = L.bounds[rank]
+        local = torch.zeros((L.per, MAX_DET, STRIDE))
+        counts = torch.zeros((L.per,), dtype=torch.int32)
         for j, i in enumerate(range(lo, hi)):
             d, n = fake_item_dets(i, items[i])
             local[j] = torch.from_numpy(d)
             counts[j] = n
         g, gc = pipeline.exchange_detections(local, counts, world)
-        q.put((rank, g.numpy().copy(), gc.numpy().copy(), len(items), per))
+        q.put((rank, g.numpy().copy(), gc.numpy().copy(), len(items), L.per))
     finally:
         dist.destroy_process_group()
 
@@ -70,20 +71,58 @@ def test_sharded_exchange_reproduces_single_process(world, n_frames):
         assert p.exitcode == 0
     got.sort(key=lambda t: t[0])
     n_items, per = got[0][3], got[0][4]
-    items = pipeline.frame_items(540, 960, pipeline.PipeConfig(slice_h=256, slice_w=256), n_frames)
-    assert n_items == len(items)
+    cfg = pipeline.PipeConfig(slice_h=256, slice_w=256, imgsz=256)
+    items = pipeline.frame_items(540, 960, cfg, n_frames)
+    L = pipeline.Layout(items, n_frames, world, pipeline.item_costs(items, cfg.imgsz))
+    assert n_items == len(items) and per == L.per
+    # blocks are contiguous, cover every item once, and no block is heavier than the optimum for a contiguous split allows
+    assert [b[0] for b in L.bounds] + [n_items] == [0] + [b[1] for b in L.bounds]
+    costs = pipeline.item_costs(items, cfg.imgsz)
+    heaviest = max(costs[lo:hi].sum() for lo, hi in L.bounds)
+    assert heaviest <= costs.sum() / world + costs.max()
     exp = np.zeros((world * per, MAX_DET, STRIDE), np.float32)
     expc = np.zeros((world * per,), np.int32)
     for i in range(n_items):
-        exp[i], expc[i] = fake_item_dets(i, items[i])
-    for _, g, gc, _, _ in got:                      # every rank holds the same, globally ordered buffer
+        exp[L.slot(i)], expc[L.slot(i)] = fake_item_dets(i, items[i])
+    for _, g, gc, _, _ in got:                      # every rank holds the same buffer, in SAHI's order (holes have count 0)
         assert np.array_equal(g, exp) and np.array_equal(gc, expc)
-    # replicated merge: same input on every rank -> same output; per-frame ranges are contiguous item ranges
+    slots = [L.slot(i) for i in range(n_items)]
+    assert slots == sorted(slots)
+    # replicated merge: same input on every rank -> same output; a frame is a contiguous slot range
     from oracle import sahi_ref
-    ipf = n_items // n_frames
     for f in range(n_frames):
-        rows = np.concatenate([exp[i, :expc[i]] for i in range(f * ipf, (f + 1) * ipf)], 0)
+        s0, ns = L.frame_slots(f, True)
+        rows = np.concatenate([exp[k, :expc[k]] for k in range(s0, s0 + ns)], 0)
+        ref_rows = np.concatenate([fake_item_dets(i, items[i])[0][:fake_item_dets(i, items[i])[1]] for i in range(f * L.ipf, (f + 1) * L.ipf)], 0)
+        assert np.array_equal(rows, ref_rows)
         dets = [sahi_ref.Det(r[:4].tolist(), r[4], 0) for r in rows]
         out = sahi_ref.postprocess(dets, "GREEDYNMM", "IOS", 0.5) if len(dets) > 1 else dets
         ys = np.asarray([d.bbox[1] for d in out])
         assert ((ys >= f * 540) & (ys < (f + 1) * 540)).all()        # frames of a super-frame never interact
+        if L.owner(f) >= 0:                                            # whole frame on one rank: its local slots hold the same rows
+            a0, an = L.frame_slots(f, False, L.owner(f))
+            lo = L.bounds[L.owner(f)][0]
+            assert [lo + a0 + k for k in range(an)] == list(range(f * L.ipf, (f + 1) * L.ipf))
+
+
+def test_layout_alignment_and_lpt():
+    """Weak scaling with whole frames per rank needs no exchange; ONE frame over the ranks does; LPT placement of SR crops is
+    deterministic and balanced."""
+    cfg = pipeline.PipeConfig()
+    for world in (2, 4, 8):
+        items = pipeline.frame_items(2160, 3840, cfg, world)
+        L = pipeline.Layout(items, world, world, pipeline.item_costs(items, 512))
+        assert L.aligned and [L.owner(f) for f in range(world)] == list(range(world))
+        assert L.rows_needed(1, 2160) == (2160, 4320)                  # a rank uploads its own frame only
+        one = pipeline.frame_items(2160, 3840, cfg, 1)
+        L1 = pipeline.Layout(one, 1, world, pipeline.item_costs(one, 512))
+        assert not L1.aligned and L1.owner(0) == -1
+        assert all(L1.rows_needed(r, 2160) == (0, 2160) for r in range(world))     # crops may come from anywhere in a spread frame
+        c1 = pipeline.item_costs(one, 512) / (512 * 512)               # 60 unit slices + one 0.5625 full-frame pass
+        assert max(c1[l:h].sum() for l, h in L1.bounds) <= -(-60 // world) + 0.5625
+    sizes = pipeline.sr_crop_sizes(32, 5).astype(np.int64)
+    a = pipeline.lpt_assign(sizes ** 2, 8)
+    assert np.array_equal(a, pipeline.lpt_assign(sizes ** 2, 8))
+    loads = np.asarray([(sizes[a == r] ** 2).sum() for r in range(8)])
+    assert loads.max() <= (sizes ** 2).sum() / 8 + (sizes ** 2).max()
+    assert set(a.tolist()) <= set(range(8))

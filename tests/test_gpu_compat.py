@@ -76,7 +76,7 @@ def test_face_enhancer_surface(compat, tmp_path):
     out, ok = enh.enhance_image(crop)
     assert ok and out.shape == (128, 144, 3)
     ref = rrdbnet_ref.enhance(rrdbnet_ref.RRDBNetRef(synth.rrdbnet_weights(4, 23), 4, 23), crop)
-    assert psnr_u8(out, ref) >= 40.0
+    assert psnr_u8(out, ref) >= 50.0
     tiny, ok = enh.enhance_image(crop[:3, :3])
     assert not ok and tiny.shape == (3, 3, 3)                     # never raises, returns the input (utils/enhancer.py:205-208)
     out2, ok = enh.enhance_image(Image.fromarray(crop[..., ::-1]))

@@ -101,4 +101,4 @@ def test_sr_config3_batch_properties(ctx):
     assert all(np.array_equal(outs_p[k], outs[perm[k]]) for k in range(32))
     # fp32 mode agrees with fp16 mode to the stated PSNR floor
     e32 = lib.Enhancer(synth.rrdbnet_weights(4, 23), 4, 23, half=False)
-    assert psnr_u8(e32.enhance(crops[3]), outs[3]) >= 40.0
+    assert psnr_u8(e32.enhance(crops[3]), outs[3]) >= 50.0

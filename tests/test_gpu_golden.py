@@ -68,4 +68,4 @@ def test_esrgan(gpu_lib):
     b = e32.enhance(z["img"], tile=16, tile_pad=4)
     assert psnr_u8(b, z["out_tiled"]) >= 55
     e16 = gpu_lib.Enhancer(W, 4, 23, half=True)
-    assert psnr_u8(e16.enhance(z["img"]), z["out"]) >= 40
+    assert psnr_u8(e16.enhance(z["img"]), z["out"]) >= 50

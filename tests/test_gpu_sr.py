@@ -1,6 +1,8 @@
 """GPU parity of the Real-ESRGAN path (C-ABI ffp_sr_*) against the oracle. north_star tolerance: SR PSNR within
 0.05 dB of the CPU path — asserted as PSNR(GPU output, oracle output) high enough that any PSNR measured against a
-third image differs by < 0.05 dB: fp32 mode >= 55 dB (|diff| <= 1 LSB, rare), fp16 mode >= 40 dB."""
+third image differs by < 0.05 dB. For uncorrelated errors dPSNR = 10*log10(1 + MSE_d/MSE_a): with the SR output ~30 dB
+from any ground truth, PSNR(GPU, oracle) >= 50 dB gives dPSNR <= 0.043 dB. Bars: fp32 mode >= 55 dB and |diff| <= 1 LSB,
+fp16 mode (the reference's half=True) >= 50 dB; test_fp16_meets_the_0p05_db_bar_directly checks the bar itself."""
 import numpy as np
 import pytest
 
@@ -34,7 +36,7 @@ def test_enhance_single(nets, gpu_lib, half):
         p = psnr_u8(out, ref)
         d = np.abs(out.astype(int) - ref.astype(int))
         if half:
-            assert p >= 40.0, p
+            assert p >= 50.0, p
         else:
             assert p >= 55.0 and d.max() <= 1, (p, d.max())
 
@@ -68,3 +70,17 @@ def test_enhance_x2_model(gpu_lib):
         r = rrdbnet_ref.enhance(ref, img)
         assert out.shape == r.shape == (2 * h, 2 * w, 3)
         assert psnr_u8(out, r) >= 55.0
+
+
+def test_fp16_meets_the_0p05_db_bar_directly(nets, gpu_lib):
+    """north_star: "SR PSNR within 0.05 dB". PSNR of the GPU output and of the oracle output against a COMMON third image (the
+    bicubic x4 of the input, a stand-in for a ground truth) must differ by less than 0.05 dB."""
+    from PIL import Image
+    from oracle import rrdbnet_ref
+    e = gpu_lib.Enhancer(nets["W4"], 4, 23, half=True)
+    for (h, w) in [(32, 32), (40, 28)]:
+        img = crop(7 * h + w, h, w)
+        third = np.asarray(Image.fromarray(img[..., ::-1]).resize((4 * w, 4 * h), Image.BICUBIC))[..., ::-1]
+        out = e.enhance(img)
+        ref = rrdbnet_ref.enhance(nets["ref4"], img)
+        assert abs(psnr_u8(out, third) - psnr_u8(ref, third)) < 0.05

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ffp.h but not exported by libffp.so"
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
-    assert lib.ffp_version() >= 100
+    assert lib.ffp_version() >= 200
 
 
 def test_slice_bboxes_matches_oracle(lib):
@@ -127,3 +127,24 @@ def test_pmc_symbol_to_variant_mapping():
     assert v("_ZN3ffp16conv_mfma_kernelIDF16_Li3ELi1ELi4ELi1ELi2ELi1ELi16EEEvNS_8ConvArgsE") == "f16_k3s1_narrow1"
     assert v("void ffp::conv_mfma_kernel<float, 1, 1, 2, 2, 2, 2, 32>(ffp::ConvArgs)") == "f32_k1s1_wideH"
     assert v("__amd_rocclr_copyBuffer") is None
+
+
+@pytest.mark.parametrize("order", ["torch_first", "libffp_first"])
+def test_single_hip_runtime(order):
+    """libffp.so, torch and RCCL must share ONE HIP runtime whatever the import order (the wheel bundles a libamdhip64 with
+    the same SONAME as the system one; two copies, or the wheel running on the system copy, is the hazard)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n" % ROOT) + (
+        "import torch\nimport ffp_amd\nfrom ffp_amd import _lib\n_lib.lib()\n" if order == "torch_first"
+        else "import ffp_amd\nfrom ffp_amd import _lib\n_lib.lib()\nimport torch\n") + (
+        "import torch.distributed\n"
+        "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+        "print(len(libs), libs)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    n, libs = out.stdout.strip().split(" ", 1)
+    assert n == "1", libs
+    import importlib.util
+    if importlib.util.find_spec("torch") is not None:
+        assert "torch" in libs            # the wheel's own copy, in both orders

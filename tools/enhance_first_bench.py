@@ -24,8 +24,8 @@ for _ in range(N):
     e = pipe.enhance_frame(frame, H, W, enh2)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    dets, counts, items = pipe.detect(e, 2 * H, 2 * W, 1)
-    rows, n = pipe.merge_frame(dets, counts, 0, items.shape[0])
+    dets, counts, L, gathered = pipe.detect(e, 2 * H, 2 * W, 1)
+    rows, n = pipe.merge_frame_of(dets, counts, L, 0, gathered)
     k = int(n.item())
     t2 = time.perf_counter()
     t_sr += t1 - t0

@@ -16,7 +16,7 @@ boxes = pipeline.crop_boxes_for_sr(np.zeros((0, 21), np.float32), H, W, 32, size
 for it in range(3):
     prof = it == 2
     pipe.det.set_profile(prof); pipe.sr.set_profile(prof)
-    d, c, _ = pipe.detect(frame, H, W, 1)
+    d, c, _, _ = pipe.detect(frame, H, W, 1)
     det_detail = pipe.det.profile_detail()
     pipe.enhance_crops(frame, H, W, boxes)
     sr_detail = pipe.sr.profile_detail()
