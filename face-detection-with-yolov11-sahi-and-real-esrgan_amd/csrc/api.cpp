@@ -564,7 +564,7 @@ int ffp_op_conv2d_time(int device, int precision, int n, int h, int w, int cin, 
       }
     }
     ConvOp o;
-    o.pc = &pc; o.stride = stride; o.act = ACT_SILU; o.up = up; o.dbg = dbg_mask; o.force_shape = force_shape;
+    o.pc = &pc; o.stride = stride; o.act = precision == FFP_PREC_F16 ? ACT_LRELU : ACT_SILU; o.up = up; o.dbg = dbg_mask; o.force_shape = force_shape;   // the activation each precision's network uses
     o.in = TView{din.p, T, pc.cin, 0, pc.cin, &lin};
     o.out = TView{dout.p, T, cout, 0, cout, &lout};
     for (int i = 0; i < 3; ++i) launch_conv(o, st);

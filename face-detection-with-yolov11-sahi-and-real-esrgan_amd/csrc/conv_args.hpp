@@ -29,6 +29,7 @@ struct ConvArgs {
   const int* up_map;
   int up_c, up_cs;
   const void* zeros;   // 256 zero bytes in device memory (padding source of the LDS-DMA loader in conv_rows.hip)
+  int ntiles_host;          // tile-loop kernels (conv_rows16.hip): tiles of an exact-mode launch (the grid no longer says)
   const int* n_tiles_dev;   // capacity-mode levels (Level::reserve): the batch's tile count lives in device memory and the grid is
                             // sized for the capacity — workgroups past n_tiles * n_nblk exit; nullptr: the grid is exact
 };
@@ -58,5 +59,10 @@ ConvArgs make_conv_args(const ConvOp& op);
 bool conv_rows_eligible(const ConvOp& op, const ConvArgs& a);
 void launch_conv_rows(ConvArgs& a, Level* out_lvl, hipStream_t st);
 void conv_rows_init();
+// k3 s1 fp16, second generation on v_mfma_f32_16x16x32_f16 (conv_rows16.hip)
+bool conv_rows16_eligible(const ConvOp& op, const ConvArgs& a);
+void launch_conv_rows16(ConvArgs& a, const PackedConv& pc, Level* out_lvl, hipStream_t st);
+void conv_rows16_init();
+bool conv_rows16_enabled();     // FFP_ROWS16=0 keeps the first-generation kernel (A/B aid)
 
 }  // namespace ffp

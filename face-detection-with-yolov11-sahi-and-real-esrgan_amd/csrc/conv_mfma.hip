@@ -11,6 +11,7 @@
 // Workgroup = 256 threads = 4 waves laid out WM x WN; a wave owns MI pixel fragments x NIW 32-channel tiles.
 // blockIdx is remapped so that the n-blocks of one pixel tile and neighbouring tiles share an XCD (L2 reuse of the
 // input tile); the mapping only affects speed.
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_args.hpp"
@@ -696,6 +697,7 @@ void conv_kernels_init() {
   static bool done = false;
   if (done) return;
   conv_rows_init();
+  conv_rows16_init();
   Family<float, 1, 1>::init(); Family<float, 3, 1>::init(); Family<float, 3, 2>::init();
   Family<_Float16, 1, 1>::init(); Family<_Float16, 3, 1>::init(); Family<_Float16, 3, 2>::init();
   Family<X3, 1, 1>::init(); Family<X3, 3, 1>::init(); Family<X3, 3, 2>::init();
@@ -762,10 +764,21 @@ ConvArgs make_conv_args(const ConvOp& op) {
   return a;
 }
 
+bool conv_rows16_enabled() {
+  static const bool on = [] { const char* e = getenv("FFP_ROWS16"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+static bool use_rows16(const ConvOp& op, const ConvArgs& a) {
+  if (!conv_rows16_eligible(op, a)) return false;
+  return a.force_shape == 9 || (a.force_shape < 0 && conv_rows16_enabled());
+}
+
 void launch_conv(const ConvOp& op, hipStream_t st) {
   const PackedConv& pc = *op.pc;
   if (conv_direct_eligible(op)) { launch_conv_direct(op, st); return; }
   ConvArgs a = make_conv_args(op);
+  if (use_rows16(op, a)) { launch_conv_rows16(a, pc, op.out.lvl, st); FFP_HIP(hipGetLastError()); return; }
   if (conv_rows_eligible(op, a)) { launch_conv_rows(a, op.out.lvl, st); FFP_HIP(hipGetLastError()); return; }
   if (pc.dt == F16) launch_t<_Float16>(a, pc.k, op.stride, op.out.lvl, st);
   else if (pc.split) launch_t<X3>(a, pc.k, op.stride, op.out.lvl, st);
@@ -777,7 +790,7 @@ int conv_tune(const ConvOp& op, hipStream_t st) {
   const PackedConv& pc = *op.pc;
   if (conv_direct_eligible(op)) return -1;
   const ConvArgs a = make_conv_args(op);
-  if (conv_rows_eligible(op, a)) return -1;
+  if (use_rows16(op, a) || conv_rows_eligible(op, a)) return -1;
   const unsigned mask = pc.dt == F16 ? valid_t<_Float16>(a, pc.k, op.stride) : pc.split ? valid_t<X3>(a, pc.k, op.stride) : valid_t<float>(a, pc.k, op.stride);
   if (__builtin_popcount(mask) < 2) return -1;
   const int heur = pc.dt == F16 ? choose_t<_Float16>(a, pc.k, op.stride, op.out.lvl)
@@ -817,6 +830,7 @@ std::string conv_variant(const ConvOp& op) {
   const PackedConv& pc = *op.pc;
   if (conv_direct_eligible(op)) return std::string(pc.dt == F32 ? "f32" : "f16") + "_k3_direct";
   const ConvArgs a = make_conv_args(op);
+  if (use_rows16(op, a)) return "f16_k3s1_rows16";
   if (conv_rows_eligible(op, a)) return "f16_k3s1_rows";
   const int shape = (op.force_shape >= 0 && op.force_shape < 6) ? op.force_shape
                     : pc.dt == F16 ? choose_t<_Float16>(a, pc.k, op.stride, op.out.lvl)

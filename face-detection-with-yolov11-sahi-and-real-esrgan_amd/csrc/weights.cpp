@@ -100,6 +100,25 @@ void pack_conv(PackedConv& pc, const std::string& name, const float* w, const fl
     FFP_HIP(hipMemcpyAsync(pc.w_direct.p, hd.data(), hd.size() * 4, hipMemcpyHostToDevice, st));
     FFP_HIP(hipStreamSynchronize(st));
   }
+  if (dt == F16 && k == 3 && cin % 32 == 0 && cout % 32 == 0) {
+    const int nt32 = cout / 32, nch = cin / 32;
+    std::vector<uint16_t> h16((size_t)nt32 * taps * nch * 2 * 64 * 8);
+    size_t o = 0;
+    for (int nt = 0; nt < nt32; ++nt)
+      for (int ch = 0; ch < nch; ++ch)
+        for (int t = 0; t < taps; ++t)
+          for (int m = 0; m < 2; ++m)
+            for (int l = 0; l < 64; ++l) {
+              const int n = nt * 32 + 8 * ((l & 15) >> 2) + 4 * m + (l & 3);
+              for (int j = 0; j < 8; ++j) {
+                const int c = ch * 32 + 8 * (l >> 4) + j;
+                h16[o++] = f32_to_f16_bits(w[((size_t)n * cin + c) * taps + t]);
+              }
+            }
+    pc.w16.alloc(h16.size() * 2);
+    FFP_HIP(hipMemcpyAsync(pc.w16.p, h16.data(), h16.size() * 2, hipMemcpyHostToDevice, st));
+    FFP_HIP(hipStreamSynchronize(st));
+  }
   const int KG = (dt == F16 || pc.split) ? 16 : 8;    // input channels per fragment group
   const int EH = KG / 2;                // elements per lane (8 halfs / 4 floats = 16 bytes)
   pc.cin_pad = (cin + KG - 1) / KG * KG;

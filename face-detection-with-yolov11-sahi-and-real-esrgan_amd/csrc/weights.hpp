@@ -34,6 +34,11 @@ struct PackedConv {
   bool split = false;   // dt == F32 only: fragments hold fp16 hi + fp16 lo parts (2 KiB each, k-group = 16) for the X3 kernels
   DevBuf w, bias;
   DevBuf w_direct;   // k3 convs with 3 real input channels (stem, conv_first): fp32 [tap][3][cout] for the direct kernel
+  // fp16 k3 convs with cin % 32 == 0 and cout % 32 == 0 (Real-ESRGAN body): A fragments of v_mfma_f32_16x16x32_f16 for
+  // conv_rows16.hip, [32-channel tile][32-channel chunk][tap][M-tile m][lane l][8 halfs]:
+  //   lane l, element j -> (n = 32*tile + 8*((l&15)>>2) + 4*m + (l&3), c = 32*chunk + 8*(l>>4) + j)
+  // (the row permutation leaves each accumulator lane with 8 consecutive output channels)
+  DevBuf w16;
   bool depthwise() const { return groups > 1; }
 };
 

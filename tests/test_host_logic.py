@@ -126,6 +126,7 @@ def test_pmc_symbol_to_variant_mapping():
     assert v("void ffp::conv_mfma_kernel<ffp::X3, 3, 1, 4, 1, 1, 1, 16>(ffp::ConvArgs)") == "f32x3_k3s1_narrow1H"
     assert v("_ZN3ffp16conv_mfma_kernelIDF16_Li3ELi1ELi4ELi1ELi2ELi1ELi16EEEvNS_8ConvArgsE") == "f16_k3s1_narrow1"
     assert v("void ffp::conv_mfma_kernel<float, 1, 1, 2, 2, 2, 2, 32>(ffp::ConvArgs)") == "f32_k1s1_wideH"
+    assert v("ffp::(anonymous namespace)::conv_rows16_kernel(ffp::ConvArgs)") == "f16_k3s1_rows16"
     assert v("__amd_rocclr_copyBuffer") is None
 
 

@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def variant(sym: str):
+    if "conv_rows16_kernel" in sym:
+        return "f16_k3s1_rows16"
     m = re.search(r"conv_rows_kernel<(\d+), *(\d+)>", sym) or re.search(r"conv_rows_kernelILi(\d+)ELi(\d+)E", sym)
     if m:
         return "f16_k3s1_rows"

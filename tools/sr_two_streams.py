@@ -26,7 +26,7 @@ def run(parts):
         tot = int(sum(((int(q[3] - q[1]) * 4) * (int(q[2] - q[0]) * 4) * 3 + 15) // 16 * 16 for q in b))
         out = torch.empty(tot, dtype=torch.uint8, device="cuda")
         offs = np.zeros(len(b) + 1, np.int64)
-        _lib._check(lib.ffp_sr_enhance_crops_dev_async(e.handle, frame.data_ptr(), H, W, _lib._ip(b), len(b), out.data_ptr(), tot,
+        _lib._check(lib.ffp_sr_enhance_crops_dev_async(e.handle, frame.data_ptr(), H, W, _lib._ip(b), len(b), 400, 10, out.data_ptr(), tot,
                                                        offs.ctypes.data_as(C.POINTER(C.c_int64))))
         outs.append(out)
     for e, _ in zip(enh, parts):
