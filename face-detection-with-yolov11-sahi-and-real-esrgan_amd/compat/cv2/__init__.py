@@ -1,0 +1,74 @@
+"""Minimal `cv2` stand-in for the reference's scripts when OpenCV is not installed (it is not a dependency of this
+build): the image-file calls they make — `cv2.imread` for the image size (pipeline_v4_yolo/app_yolo_sahi.py:37-42),
+`cv2.imwrite` with `[cv2.IMWRITE_JPEG_QUALITY, q]` (utils/enhancer.py:273-278), `cv2.cvtColor` BGR<->RGB, `cv2.resize` —
+on Pillow + numpy, BGR arrays like OpenCV's. A real OpenCV further down sys.path always wins: this module then
+re-exports it untouched. Drawing primitives are not provided (utils.visualization of this build draws with Pillow).
+"""
+import importlib.machinery
+import importlib.util
+import os
+import sys
+
+_here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _real_cv2():
+    for p in sys.path:
+        if not p or os.path.abspath(p) == _here:
+            continue
+        spec = importlib.machinery.PathFinder.find_spec("cv2", [p])
+        if spec is not None and spec.origin and os.path.dirname(os.path.dirname(os.path.abspath(spec.origin))) != _here:
+            return spec
+    return None
+
+
+_spec = _real_cv2()
+if _spec is not None:                                   # OpenCV is installed: be it
+    _mod = importlib.util.module_from_spec(_spec)
+    sys.modules[__name__] = _mod
+    _spec.loader.exec_module(_mod)
+else:
+    import numpy as np
+    from PIL import Image
+
+    __version__ = "0.0-ffp-shim"
+    IMREAD_COLOR, IMREAD_UNCHANGED = 1, -1
+    IMWRITE_JPEG_QUALITY, IMWRITE_PNG_COMPRESSION = 1, 16
+    COLOR_BGR2RGB, COLOR_RGB2BGR = 4, 4
+    INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 0, 1, 2, 3, 4
+
+    def imread(path, flags=IMREAD_COLOR):
+        """HxWx3 uint8 BGR, or None when the file cannot be read (OpenCV's convention: no exception)."""
+        try:
+            return np.asarray(Image.open(path).convert("RGB"))[..., ::-1].copy()
+        except Exception:
+            return None
+
+    def imwrite(path, img, params=None):
+        """JPEG quality from [IMWRITE_JPEG_QUALITY, q] (OpenCV default 95). Returns success like OpenCV."""
+        try:
+            q = 95
+            if params:
+                for k, v in zip(params[0::2], params[1::2]):
+                    if k == IMWRITE_JPEG_QUALITY:
+                        q = int(v)
+            a = np.ascontiguousarray(img)
+            pil = Image.fromarray(a[..., ::-1] if a.ndim == 3 and a.shape[2] == 3 else a)
+            if os.path.splitext(path)[1].lower() in (".jpg", ".jpeg"):
+                pil.save(path, quality=q)
+            else:
+                pil.save(path)
+            return True
+        except Exception:
+            return False
+
+    def cvtColor(img, code):
+        if code != COLOR_BGR2RGB:
+            raise NotImplementedError("cv2 shim: only BGR<->RGB")
+        return np.ascontiguousarray(img[..., ::-1])
+
+    def resize(img, dsize, fx=0, fy=0, interpolation=INTER_LINEAR):
+        w, h = dsize if dsize and dsize[0] > 0 else (int(round(img.shape[1] * fx)), int(round(img.shape[0] * fy)))
+        mode = {INTER_NEAREST: Image.NEAREST, INTER_LINEAR: Image.BILINEAR, INTER_CUBIC: Image.BICUBIC, INTER_AREA: Image.BOX,
+                INTER_LANCZOS4: Image.LANCZOS}[interpolation]
+        return np.asarray(Image.fromarray(np.ascontiguousarray(img)).resize((w, h), mode))

@@ -9,7 +9,7 @@ What it restates (each function cites the reference file:line it follows):
     ultra_post.py   LetterBox, DFL/box/keypoint decode, non_max_suppression, scale_boxes/scale_coords      numpy / torch fp32
     sahi_ref.py     get_slice_bboxes, nms, greedy_nmm, merge, get_prediction / get_sliced_prediction        numpy + python
     rrdbnet_ref.py  RRDBNet forward + RealESRGANer.enhance (utils/enhancer.py:121-156,214)                  torch CPU fp32
-    wrapper_ref.py  YOLOv11PoseDetectionModel result conversion (utils/yolo_wrapper.py:84-166)              python
+    wrapper_ref.py  YOLOv11PoseDetectionModel result conversion + keypoint cache / attach (utils/yolo_wrapper.py:84-217)  python
 
 PARITY UNPINNED against the reference's own outputs: the arithmetic of this path lives in third-party packages
 that are neither vendored under /root/reference nor installed here (ultralytics — unpinned/unlisted;

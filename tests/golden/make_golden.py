@@ -71,6 +71,27 @@ def main():
     lb = ultra_post.letterbox(frame, 128)
     small = ultra_post.resize_linear_u8(frame, 100, 70)
     np.savez_compressed(os.path.join(HERE, "letterbox.npz"), frame_seed=21, frame_hw=(160, 224), letterbox128=lb, resize_100x70=small)
+    # 7. real-image fixtures (tests/golden/real/*.png, cut by make_real_fixtures.py from the reference's leftover run data): detector
+    #    on photographs (native, down-scaling and up-scaling letterbox), Real-ESRGAN x4 on face crops the reference's own run saved
+    from PIL import Image
+    real = os.path.join(HERE, "real")
+    save = {}
+    cases = [("det_test1", None, 256), ("det_parade", None, 256), ("det_family", None, 256), ("det_photo4k", None, 256),
+             ("det_test1", (96, 40, 224, 168), 256), ("det_parade", (20, 60, 180, 200), 320)]
+    for k, (name, sub, imgsz) in enumerate(cases):
+        img = np.asarray(Image.open(os.path.join(real, name + ".png")).convert("RGB"))       # what SAHI hands the wrapper: RGB ndarray
+        if sub is not None:
+            img = img[sub[1]:sub[3], sub[0]:sub[2]]
+        r = ultra_post.predict(ref, img, imgsz, 0.25, 0.7, 300)
+        raw = ref.forward(ultra_post.preprocess(img, imgsz))[0].numpy()
+        save[f"case{k}_xyxy"] = r.xyxy; save[f"case{k}_conf"] = r.conf; save[f"case{k}_kpts"] = r.kpts
+        save[f"case{k}_cls_row"] = raw[4].astype(np.float32)
+        save[f"case{k}_box_rows"] = raw[:4].astype(np.float16)        # fp16 storage: tolerance 2e-2 px in the test
+    save["cases"] = np.asarray([f"{n}|{'' if s_ is None else ','.join(map(str, s_))}|{i}" for n, s_, i in cases])
+    for name in ("sr_face_20x28", "sr_face_23x27", "sr_face_47x54"):
+        bgr = np.asarray(Image.open(os.path.join(real, name + ".png")).convert("RGB"))[..., ::-1].copy()
+        save[name] = rrdbnet_ref.enhance(net, bgr)
+    np.savez_compressed(os.path.join(HERE, "real_expected.npz"), **save)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

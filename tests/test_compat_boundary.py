@@ -1,0 +1,170 @@
+"""CPU tests of the drop-in boundary that need no GPU: the LITERAL import blocks of the two callers north_star names resolve
+against the compat shims, the adapter's result conversion + keypoint side channel agree with the oracle
+(/root/reference/utils/yolo_wrapper.py:84-217), and the presentation helpers write what the reference's scripts expect
+(/root/reference/utils/visualization.py:78-285)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# pipeline_v4_yolo/app_yolo_sahi.py:1-17 (the sys.path line points at the reference's root; here: the shim directory)
+APP_YOLO_SAHI_IMPORTS = """
+import sys
+import os
+import time
+import cv2
+from pathlib import Path
+from glob import glob
+
+from sahi.predict import get_sliced_prediction
+from utils.yolo_wrapper import YOLOv11PoseDetectionModel
+from utils.visualization import (
+    draw_detections, 
+    save_face_crops, 
+    create_detection_summary
+)
+"""
+# pipeline_v1_detection_first/app_v1.py:1-14
+APP_V1_IMPORTS = """
+import os
+import re
+import time
+import os, sys
+
+from sahi.predict import get_sliced_prediction
+from utils.insightface_wrapper import InsightFaceDetectionModel
+from utils.visualization import draw_detections, save_face_crops, create_detection_summary
+from utils.enhancer import FaceEnhancer, enhance_face_crops_batch, create_enhancement_summary
+from PIL import Image
+"""
+
+
+@pytest.mark.parametrize("block", [APP_YOLO_SAHI_IMPORTS, APP_V1_IMPORTS], ids=["app_yolo_sahi", "app_v1"])
+def test_literal_import_blocks_resolve(block):
+    code = ("import sys; sys.path.insert(0, %r)\nimport ffp_amd\nfrom ffp_amd import compat\ncompat.install()\n" % ROOT) + block + (
+        "\nimport cv2 as _c\nassert hasattr(_c, 'imread') and hasattr(_c, 'imwrite') and hasattr(_c, 'IMWRITE_JPEG_QUALITY')\nprint('ok')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+@pytest.fixture(scope="module")
+def shims():
+    import ffp_amd  # noqa: F401
+    from ffp_amd import compat
+    compat.install()
+    return compat
+
+
+def fake_results(rng, n, w, h):
+    from utils.yolo_wrapper import Results
+    rows = np.zeros((n, 21), np.float32)
+    x1 = rng.uniform(0, w - 30, n); y1 = rng.uniform(0, h - 30, n)
+    rows[:, 0], rows[:, 1] = x1, y1
+    rows[:, 2], rows[:, 3] = x1 + rng.uniform(8, 29.9, n), y1 + rng.uniform(8, 29.9, n)
+    rows[:, 4] = rng.uniform(0.05, 0.99, n)
+    rows[:, 6:] = rng.uniform(0, 100, (n, 15))
+    return Results(rows, 5, (h, w), {0: "face"}), rows
+
+
+def test_adapter_conversion_and_keypoint_attach_match_oracle(shims):
+    """a5 + a8: truncation, shift, no second confidence filter, cache keys, exact-key and best-IoU (> 0.5, first wins) attach."""
+    from oracle import wrapper_ref
+    from sahi.prediction import ObjectPrediction
+    from utils.yolo_wrapper import YOLOv11PoseDetectionModel
+    rng = np.random.default_rng(11)
+    m = YOLOv11PoseDetectionModel(model_path="unused", confidence_threshold=0.5, device="cuda:0", image_size=256, load_at_init=False)
+    cache = {}
+    all_preds, all_ref = [], []
+    for shift in ([0, 0], [410, 0], [820, 410], [3328, 1648]):
+        res, rows = fake_results(rng, 7, 512, 512)
+        m._original_predictions = [res]
+        m.convert_original_predictions(shift_amount=shift, full_shape=[2160, 3840])       # SAHI passes flat lists (docs sahi/base.py:176-179)
+        got = m.object_prediction_list
+        ref = wrapper_ref.convert(rows[:, :4], rows[:, 4], rows[:, 6:].reshape(-1, 5, 3), shift, [2160, 3840], cache)
+        assert len(got) == len(ref) == 7                                                     # scores below the threshold are NOT dropped here
+        for p, (bx, sc, sh) in zip(got, ref):
+            assert p.bbox.to_xyxy() == bx and p.score.value == pytest.approx(sc) and p.bbox.shift_amount == sh
+            assert p.category.id == 0 and p.category.name == "face"
+        all_preds += [p.get_shifted_object_prediction() for p in got]
+        all_ref += [[b[0] + s[0], b[1] + s[1], b[2] + s[0], b[3] + s[1]] for b, _, s in ref]
+    assert set(m.keypoints_cache) == set(cache)
+    for k in cache:
+        assert np.array_equal(m.keypoints_cache[k], cache[k])
+    # nested-list form of the arguments (utils/yolo_wrapper.py:99-118) gives the same list
+    m2 = YOLOv11PoseDetectionModel(model_path="unused", load_at_init=False)
+    res, rows = fake_results(rng, 3, 512, 512)
+    m2._original_predictions = [res]
+    m2._create_object_prediction_list_from_original_predictions([[5, 6]], [[2160, 3840]])
+    a = [p.bbox.to_xyxy() for p in m2.object_prediction_list]
+    m2._original_predictions = [res]
+    m2._create_object_prediction_list_from_original_predictions([5, 6], [2160, 3840])
+    assert a == [p.bbox.to_xyxy() for p in m2.object_prediction_list]
+    # attach: exact boxes, grown (merged) boxes that still overlap > 0.5, boxes that overlap nothing
+    boxes = [p.bbox.to_voc_bbox() for p in all_preds]
+    assert boxes == all_ref
+    grown = [[b[0] - 2, b[1] - 1, b[2] + 3, b[3] + 2] for b in boxes[::3]]
+    far = [[3000, 2000, 3040, 2050], [1, 1, 9, 9]]
+    query = boxes + [[max(v, 0) for v in g] for g in grown] + far
+    preds = [ObjectPrediction(bbox=q, category_id=0, category_name="face", score=0.9) for q in query]
+    out = m.attach_keypoints_to_predictions(preds)
+    ref = wrapper_ref.attach(query, cache)
+    assert out is preds
+    n_att = 0
+    for p, r in zip(out, ref):
+        if r is None:
+            assert not hasattr(p, "keypoints")
+        else:
+            assert p.keypoints.shape == (5, 3) and np.array_equal(p.keypoints, r)
+            n_att += 1
+    assert n_att >= len(boxes) + len(grown) - 2 and not hasattr(out[-1], "keypoints")
+    for q in (query[0], query[len(boxes)], far[0]):                                         # the lookup app_yolo_sahi.py:80-84 calls
+        r = wrapper_ref.attach([q], cache)[0]
+        k = m.get_keypoints_for_bbox(q)
+        assert (k is None) == (r is None) and (k is None or np.array_equal(k, r))
+    # empty result convention (:95-97) and cache reset on unload (:58-61)
+    m._original_predictions = [fake_results(rng, 0, 64, 64)[0]]
+    m.convert_original_predictions(shift_amount=[0, 0], full_shape=[64, 64])
+    assert m.object_prediction_list == []
+    m.unload_model()
+    assert m.keypoints_cache == {} and m.model is None
+
+
+def test_presentation_helpers_write_the_reference_outputs(shims, tmp_path):
+    from PIL import Image
+    from sahi.prediction import ObjectPrediction, PredictionResult
+    from utils.visualization import (FACE_KEYPOINT_NAMES, create_detection_summary, draw_detections, draw_detections_on_image,
+                                     save_face_crops)
+    import cv2
+    img = (np.random.default_rng(3).integers(0, 255, (120, 160, 3))).astype(np.uint8)
+    path = str(tmp_path / "in.png")
+    assert cv2.imwrite(path, img) and np.array_equal(cv2.imread(path), img)                 # shim round trip, BGR in / BGR out
+    assert cv2.imread(str(tmp_path / "missing.png")) is None
+    preds = [ObjectPrediction(bbox=[10, 20, 50, 70], category_id=0, category_name="face", score=0.876),
+             ObjectPrediction(bbox=[140, 100, 200, 150], category_id=0, category_name="face", score=0.512),     # clamped to 160 x 120
+             ObjectPrediction(bbox=[30, 30, 30, 60], category_id=0, category_name="face", score=0.7)]           # empty: skipped
+    preds[0].keypoints = np.asarray([[20, 30, 0.9], [40, 30, 0.8], [30, 45, 0.7], [22, 60, 0.2], [38, 60, 0.95]], np.float32)
+    res = PredictionResult(object_prediction_list=preds, image=path, durations_in_seconds={})
+    crops = save_face_crops(path, res, str(tmp_path / "crop"), prefix="t_face")
+    assert [os.path.basename(c) for c in crops] == ["t_face_1_conf_0.88.jpg", "t_face_2_conf_0.51.jpg"]
+    assert Image.open(crops[0]).size == (40, 50) and Image.open(crops[1]).size == (20, 20)
+    out = str(tmp_path / "viz" / "o.jpg")
+    draw_detections(path, res, out, show_confidence=True, show_keypoints=True, box_color=(0, 255, 0), text_color=(255, 255, 255),
+                    kpt_conf_threshold=0.3)
+    assert Image.open(out).size == (160, 120)
+    over = draw_detections_on_image(img, res, draw_skeleton=True)
+    assert over.shape == img.shape and (over != img).any() and (over[25:70, 10] == (0, 255, 0)).all(1).sum() >= 40      # left edge of box 1, BGR green
+    s = str(tmp_path / "sum" / "s.txt")
+    create_detection_summary(res, path, 1.234, s, 160, 120, 640, 640)
+    text = open(s, encoding="utf-8").read().splitlines()
+    assert text[1] == "=== Ringkasan Deteksi Wajah dengan Keypoints ===" and "Gambar Sumber: in.png" in text
+    assert "Ukuran Gambar Asli: 160x120 px" in text and "Ukuran Slice: 640x640 px" in text and "Waktu Proses Total: 1.23 detik" in text
+    assert "Total Wajah Ditemukan: 3" in text and "Rata-rata Skor Kepercayaan: 0.696" in text
+    assert "  - Bounding Box: [x1: 10, y1: 20, x2: 50, y2: 70]" in text and "  - Skor Kepercayaan: 0.876" in text
+    assert f"      {FACE_KEYPOINT_NAMES[0]}: (20.0, 30.0) [conf: 0.900]" in text
+    empty = PredictionResult(object_prediction_list=[], image=path, durations_in_seconds={})
+    create_detection_summary(empty, path, 0.5, s, 160, 120, 640, 640)
+    assert "Tidak ada wajah yang terdeteksi." in open(s, encoding="utf-8").read()
