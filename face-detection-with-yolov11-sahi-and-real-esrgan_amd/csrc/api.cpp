@@ -498,6 +498,15 @@ int ffp_op_conv2d(int device, int precision, const float* x, int n, int h, int w
     if (res) dres = to_dev(res, npx_out, cout, cout);
     DevBuf dout(npx_out * cout * dsize(T) + 256);
     TView vin{din.p, T, cin_s, 0, cin_s, &lin}, vout{dout.p, T, cout, 0, cout, &lout}, vres{dres.p, T, cout, 0, cout, &lout};
+    DevBuf slots(2 * sizeof(unsigned));                 // max-|value| slots of the input / output buffers (scaled split, see TView::amax)
+    {
+      float m = 0.f;
+      for (size_t i = 0; i < npx_in * (size_t)cin; ++i) m = std::max(m, std::fabs(x[i]));
+      unsigned hb[2] = {0u, 0u};
+      std::memcpy(&hb[0], &m, 4);
+      FFP_HIP(hipMemcpy(slots.p, hb, sizeof(hb), hipMemcpyHostToDevice));
+      vin.amax = slots.as<unsigned>(); vout.amax = slots.as<unsigned>() + 1;
+    }
     if (pc.depthwise()) {
       FFP_CHECK(k == 3 && stride == 1 && !up, FFP_ERR_ARG, "conv2d: depthwise is 3x3 stride 1");
       DwConvOp o;

@@ -142,6 +142,9 @@ struct TView {
   DType dt = F32;
   int cs = 0, coff = 0, C = 0;
   Level* lvl = nullptr;
+  // device slot holding the bit pattern of max |value| over the whole BUFFER this view belongs to (every producer of a slice
+  // raises it with an atomic max; reset per inference): the tensor-wide exponent of the scaled fp16 hi/lo split (FFP_PREC_F32X3)
+  unsigned* amax = nullptr;
   TView slice(int c0, int c) const { TView v = *this; v.coff += c0; v.C = c; return v; }
 };
 

@@ -29,6 +29,13 @@ struct ConvArgs {
   const int* up_map;
   int up_c, up_cs;
   const void* zeros;   // 256 zero bytes in device memory (padding source of the LDS-DMA loader in conv_rows.hip)
+  // scaled split (FFP_PREC_F32X3): the loader multiplies the activations by 2^(13 - e), e = exponent of max(*amax_in, *amax_in2),
+  // before cutting them into fp16 hi + lo parts; the weights were packed with a per-output-channel power of two (oscale = its
+  // inverse); the epilogue multiplies the sums back and raises *amax_out to the largest |output| it stores
+  const unsigned* amax_in;
+  const unsigned* amax_in2;
+  unsigned* amax_out;
+  const float* oscale;
   int ntiles_host;          // tile-loop kernels (conv_rows16.hip): tiles of an exact-mode launch (the grid no longer says)
   const int* n_tiles_dev;   // capacity-mode levels (Level::reserve): the batch's tile count lives in device memory and the grid is
                             // sized for the capacity — workgroups past n_tiles * n_nblk exit; nullptr: the grid is exact
@@ -43,6 +50,22 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   // blocks b and b+8 share an XCD (observed round-robin dispatch): give each XCD a contiguous run of logical ids.
   const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+// raise a max-|value| slot (see TView::amax): wave-wide maximum first, and the atomic only when it would change the slot
+__device__ __forceinline__ void raise_amax(unsigned* slot, float mx) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  const unsigned b = __float_as_uint(mx);
+  if ((threadIdx.x & 63) == 0 && b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
+}
+
+// activation scale of the split and its inverse from a max-|value| bit pattern: 2^(13 - e) puts the largest value in [2^13, 2^14)
+__device__ __forceinline__ void split_scales(unsigned amax_bits, float* t, float* tinv) {
+  const unsigned eb = (amax_bits >> 23) & 0xFFu;
+  const bool ok = eb >= 14u && eb < 255u;         // zero / denormal-tiny / inf / nan tensors: unscaled
+  *t = ok ? __uint_as_float((267u - eb) << 23) : 1.f;
+  *tinv = ok ? __uint_as_float((eb - 13u) << 23) : 1.f;
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {

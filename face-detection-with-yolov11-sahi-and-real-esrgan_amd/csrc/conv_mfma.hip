@@ -197,6 +197,16 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
     return make_uint4(v[0], v[1], v[2], v[3]);
   };
 
+  // scaled split: tensor-wide power of two of the activations (max |value| of the input buffer(s) -> [2^13, 2^14) in fp16)
+  float tscale = 1.f, tinv = 1.f;
+  if constexpr (SPLIT) {
+    if (a.amax_in) {
+      unsigned m = *a.amax_in;
+      if (a.amax_in2) m = max(m, *a.amax_in2);
+      split_scales((unsigned)__builtin_amdgcn_readfirstlane((int)m), &tscale, &tinv);
+    }
+  }
+
   // per-thread staging slots: which vector each of this thread's RI + RW registers carries (chunk independent part)
   unsigned isrc[RI];           // byte offset of the pixel record relative to the resource base (OOB: zero fill)
   int ivec[RI];                // vector index inside the chunk
@@ -274,7 +284,8 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
       const int idx = tid + i * 256;
       if (idx < G::NVI) {
         if (SPLIT) {   // 4 floats -> 4 fp16 hi parts + 4 fp16 residuals, stored in the hi / lo halves of the pixel record
-          const float f[4] = {__uint_as_float(qi[i].x), __uint_as_float(qi[i].y), __uint_as_float(qi[i].z), __uint_as_float(qi[i].w)};
+          const float f[4] = {__uint_as_float(qi[i].x) * tscale, __uint_as_float(qi[i].y) * tscale, __uint_as_float(qi[i].z) * tscale,
+                              __uint_as_float(qi[i].w) * tscale};
           union { uint2 u; _Float16 h[4]; } hi, lo;
 #pragma unroll
           for (int q = 0; q < 4; ++q) { hi.h[q] = (_Float16)f[q]; lo.h[q] = (_Float16)(f[q] - (float)hi.h[q]); }
@@ -301,13 +312,23 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
-  // bias for this lane's 16 channels of each 32-channel tile: fetched now, consumed in the epilogue (no exposed L2 round trip there)
-  float4 bias_r[NIW][4];
+  // bias (and, for the split, the per-channel output scale) in the ROW order of epilogue A — lane % LPP picks CPL consecutive
+  // channels of each 32-channel tile: fetched now, consumed after the LDS round trip (no exposed L2 round trip there)
+  constexpr int CPL_A = 16 / ES, LPP_A = 32 / CPL_A;
+  float bias_l[NIW][CPL_A], osc_l[NIW][CPL_A];
 #pragma unroll
-  for (int ni = 0; ni < NIW; ++ni)
+  for (int ni = 0; ni < NIW; ++ni) {
+    const int chb = min(ntile0 + ni, a.ntiles32 - 1) * 32 + (lane % LPP_A) * CPL_A;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      bias_r[ni][g] = *reinterpret_cast<const float4*>(a.bias + min(ntile0 + ni, a.ntiles32 - 1) * 32 + 8 * g + 4 * hh);
+    for (int q = 0; q < CPL_A; q += 4) {
+      const float4 bv = *reinterpret_cast<const float4*>(a.bias + chb + q);
+      bias_l[ni][q] = bv.x; bias_l[ni][q + 1] = bv.y; bias_l[ni][q + 2] = bv.z; bias_l[ni][q + 3] = bv.w;
+      float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
+      if constexpr (SPLIT) { if (a.oscale) sv = *reinterpret_cast<const float4*>(a.oscale + chb + q); }
+      osc_l[ni][q] = sv.x * tinv; osc_l[ni][q + 1] = sv.y * tinv; osc_l[ni][q + 2] = sv.z * tinv; osc_l[ni][q + 3] = sv.w * tinv;
+    }
+  }
+  float amax_run = 0.f;                               // largest |value| this lane stores (raise_amax at the end)
 
   // One step = one (k-group, tap): MI pixel fragments + NIW weight fragments -> NIW x MI MFMAs. The fragments of step
   // s + PD are requested from LDS before the MFMAs of step s issue (explicit register ring, everything unrolled): with one
@@ -428,13 +449,8 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int ch = 8 * g + 4 * hh;
-          const float4 bv = bias_r[ni][g];
-          float4 v;
-          v.x = apply_act(acc[ni][mi][4 * g + 0] + bv.x, a.act);
-          v.y = apply_act(acc[ni][mi][4 * g + 1] + bv.y, a.act);
-          v.z = apply_act(acc[ni][mi][4 * g + 2] + bv.z, a.act);
-          v.w = apply_act(acc[ni][mi][4 * g + 3] + bv.w, a.act);
-          *reinterpret_cast<float4*>(et + p * EROW + ch * 4) = v;
+          *reinterpret_cast<float4*>(et + p * EROW + ch * 4) =
+              make_float4(acc[ni][mi][4 * g + 0], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS is in order per wave; make the tile visible to all lanes
 #pragma unroll
@@ -447,6 +463,11 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
             const float4 t4 = *reinterpret_cast<const float4*>(et + pp * EROW + (ch0 + 4 * q) * 4);
             v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
           }
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) {
+            if constexpr (SPLIT) v[q] = apply_act(fmaf(v[q], osc_l[ni][q], bias_l[ni][q]), a.act);
+            else v[q] = apply_act(v[q] + bias_l[ni][q], a.act);
+          }
           if (a.res1) {
             const GT* r = reinterpret_cast<const GT*>(&r1v[it]);
 #pragma unroll
@@ -457,6 +478,10 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
 #pragma unroll
             for (int q = 0; q < CPL; ++q) v[q] = v[q] * a.s2 + (float)r[q];
           }
+          if constexpr (SPLIT) {
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) amax_run = fmaxf(amax_run, fabsf(v[q]));
+          }
           uint4 ov;
           GT* o = reinterpret_cast<GT*>(&ov);
 #pragma unroll
@@ -465,6 +490,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
         }
       }
     }
+    if constexpr (SPLIT) { if (a.amax_out) raise_amax(a.amax_out, amax_run); }
     return;
   }
 
@@ -492,11 +518,20 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
         const int ch = nt * 32 + 8 * g + 4 * hh;
         if (ch >= a.cout) continue;
         float v[4];
-        const float4 bv = bias_r[ni][g];
-        v[0] = acc[ni][mi][4 * g + 0] + bv.x;
-        v[1] = acc[ni][mi][4 * g + 1] + bv.y;
-        v[2] = acc[ni][mi][4 * g + 2] + bv.z;
-        v[3] = acc[ni][mi][4 * g + 3] + bv.w;
+        const float4 bv = *reinterpret_cast<const float4*>(a.bias + ch);      // bias is padded to 32 channels per tile
+        if constexpr (SPLIT) {
+          float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (a.oscale) sv = *reinterpret_cast<const float4*>(a.oscale + ch);
+          v[0] = fmaf(acc[ni][mi][4 * g + 0], sv.x * tinv, bv.x);
+          v[1] = fmaf(acc[ni][mi][4 * g + 1], sv.y * tinv, bv.y);
+          v[2] = fmaf(acc[ni][mi][4 * g + 2], sv.z * tinv, bv.z);
+          v[3] = fmaf(acc[ni][mi][4 * g + 3], sv.w * tinv, bv.w);
+        } else {
+          v[0] = acc[ni][mi][4 * g + 0] + bv.x;
+          v[1] = acc[ni][mi][4 * g + 1] + bv.y;
+          v[2] = acc[ni][mi][4 * g + 2] + bv.z;
+          v[3] = acc[ni][mi][4 * g + 3] + bv.w;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], a.act);
         const bool vec = a.vec_ok && ch + 3 < a.cout;
@@ -516,6 +551,10 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = v[j] * a.s2 + r[j];
         }
+        if constexpr (SPLIT) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (ch + j < a.cout) amax_run = fmaxf(amax_run, fabsf(v[j]));
+        }
         const size_t oidx = (size_t)gp * a.out_cs + a.out_coff + ch;
         if (a.out_f32) {
           float* op = reinterpret_cast<float*>(a.out) + oidx;
@@ -529,6 +568,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
       }
     }
   }
+  if constexpr (SPLIT) { if (a.amax_out) raise_amax(a.amax_out, amax_run); }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------
@@ -756,6 +796,15 @@ ConvArgs make_conv_args(const ConvOp& op) {
     a.up_c = op.up2_c; a.up_cs = op.up2.cs;
     FFP_CHECK(a.up_map != nullptr, FFP_ERR_STATE, "conv %s: x2-source map missing", pc.name.c_str());
   }
+  a.amax_in = a.amax_in2 = nullptr; a.amax_out = nullptr; a.oscale = nullptr;
+  if (pc.split) {
+    a.oscale = pc.oscale.as<float>();
+    a.amax_in = op.in.amax;
+    a.amax_in2 = op.has_up2 ? op.up2.amax : nullptr;
+    a.amax_out = op.out.amax;
+    FFP_CHECK(!op.has_up2 || (op.in.amax != nullptr) == (op.up2.amax != nullptr), FFP_ERR_STATE, "conv %s: both sources need a max-|value| slot", pc.name.c_str());
+  }
+  a.ntiles_host = 0;
   a.dbg = op.dbg;
   a.force_shape = op.force_shape;
   a.zeros = zero_block();

@@ -75,7 +75,31 @@ TView Plan::alloc(Level* l, int C, DType dt) {
   bytes += nb;
   TView v;
   v.ptr = bufs.back().p; v.dt = dt; v.cs = C; v.coff = 0; v.C = C; v.lvl = l;
+  if (!amax_slots.p) amax_slots.alloc(sizeof(unsigned) * AMAX_CAP);
+  FFP_CHECK((int)amax_init.size() < AMAX_CAP, FFP_ERR_STATE, "plan: more than %d buffers", AMAX_CAP);
+  v.amax = amax_slots.as<unsigned>() + amax_init.size();
+  amax_init.push_back(0u);
   return v;
+}
+
+void Plan::set_amax_bound(const TView& v, float bound) {
+  FFP_CHECK(v.amax && amax_slots.p, FFP_ERR_STATE, "plan: view has no max-|value| slot");
+  unsigned b;
+  std::memcpy(&b, &bound, 4);
+  amax_init[v.amax - amax_slots.as<unsigned>()] = b;
+}
+
+void Plan::add_amax_reset(hipStream_t st) {
+  if (amax_init.empty()) return;
+  amax_init_dev.alloc(sizeof(unsigned) * amax_init.size());
+  FFP_HIP(hipMemcpyAsync(amax_init_dev.p, amax_init.data(), sizeof(unsigned) * amax_init.size(), hipMemcpyHostToDevice, st));
+  FFP_HIP(hipStreamSynchronize(st));
+  unsigned* slots = amax_slots.as<unsigned>();
+  const unsigned* init = amax_init_dev.as<unsigned>();
+  const int n = (int)amax_init.size();
+  Step s;
+  s.run = [slots, init, n](hipStream_t q) { launch_amax_init(slots, init, n, q); };
+  steps.insert(steps.begin(), std::move(s));
 }
 
 void Plan::add_conv(const ConvOp& op) {

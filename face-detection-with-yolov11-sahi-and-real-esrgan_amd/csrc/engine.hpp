@@ -43,6 +43,12 @@ struct Plan {
   double conv_flops = 0;
   int conv_launches = 0;
   size_t bytes = 0;
+  // max-|value| slots, one per allocated buffer (TView::amax): reset to `amax_init` by the first step of the plan
+  static constexpr int AMAX_CAP = 512;
+  DevBuf amax_slots, amax_init_dev;
+  std::vector<unsigned> amax_init;
+  void set_amax_bound(const TView& v, float bound);      // a bound known without looking at data (image inputs, stem output)
+  void add_amax_reset(hipStream_t st);                   // uploads the initial values and appends the reset step
   // The launch sequence of a plan is fixed (every pointer is plan-owned), so after one eager run it is captured into a
   // hipGraph and replayed: ~110 (detector) / ~355 (SR) launches per frame become one graph launch.
   hipGraph_t graph = nullptr;

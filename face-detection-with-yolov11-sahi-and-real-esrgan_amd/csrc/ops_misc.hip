@@ -83,10 +83,31 @@ __global__ void dwconv3x3_kernel(const T* __restrict__ in, int in_cs, int in_cof
 // instead of four (the per-pixel form runs at ~40 % of its HBM roofline on the stride-8 cls-tower layers). Taps are
 // accumulated in the same (ky, kx) order with zeros for out-of-image taps: bit-identical to dwconv3x3_kernel.
 template <typename T>
+__device__ __forceinline__ void dwconv_strip_body(const T* __restrict__ in, int in_cs, int in_coff, int grp, int grp_stride, int grp_off,
+                                                  T* __restrict__ out, int out_cs, int out_coff, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, const T* __restrict__ res, int r_cs, int r_coff, int C,
+                                                  int act, const int4* __restrict__ tab, int n_img, long long total_px, float& mx);
+
+template <typename T>
 __global__ void dwconv3x3_strip_kernel(const T* __restrict__ in, int in_cs, int in_coff, int grp, int grp_stride, int grp_off,
                                        T* __restrict__ out, int out_cs, int out_coff, const float* __restrict__ w /*[9][C]*/,
                                        const float* __restrict__ bias, const T* __restrict__ res, int r_cs, int r_coff, int C,
-                                       int act, const int4* __restrict__ tab, int n_img, long long total_px) {
+                                       int act, const int4* __restrict__ tab, int n_img, long long total_px, unsigned* __restrict__ amax) {
+  float mx = 0.f;                        // largest |value| this thread stores (see TView::amax)
+  dwconv_strip_body<T>(in, in_cs, in_coff, grp, grp_stride, grp_off, out, out_cs, out_coff, w, bias, res, r_cs, r_coff, C, act, tab, n_img, total_px, mx);
+  if (amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const unsigned b = __float_as_uint(mx);
+    if ((threadIdx.x & 63) == 0 && b > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, b);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void dwconv_strip_body(const T* __restrict__ in, int in_cs, int in_coff, int grp, int grp_stride, int grp_off,
+                                       T* __restrict__ out, int out_cs, int out_coff, const float* __restrict__ w /*[9][C]*/,
+                                       const float* __restrict__ bias, const T* __restrict__ res, int r_cs, int r_coff, int C,
+                                       int act, const int4* __restrict__ tab, int n_img, long long total_px, float& mx) {
   const int C4 = C >> 2;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long groups = (total_px + 3) >> 2;
@@ -107,6 +128,7 @@ __global__ void dwconv3x3_strip_kernel(const T* __restrict__ in, int in_cs, int 
       const float4 r = ld4<T>(res + (size_t)gp * r_cs + r_coff + c);
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     }
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     st4<T>(out + (size_t)gp * out_cs + out_coff + c, v);
   };
   if (x0 + 3 < t0.z) {          // the four pixels sit in one row of one image
@@ -626,12 +648,32 @@ void launch_dwconv(const DwConvOp& op, hipStream_t st) {
     hipLaunchKernelGGL(dwconv3x3_strip_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)op.in.ptr, op.in.cs, op.in.coff, grp,
                        gstride, op.grp_off, (float*)op.out.ptr, op.out.cs, op.out.coff, pc.w.as<float>(), pc.bias.as<float>(),
                        op.has_res ? (const float*)op.res.ptr : nullptr, op.res.cs, op.res.coff, C, op.act, tab, op.out.lvl->n,
-                       op.out.lvl->total_px);
+                       op.out.lvl->total_px, op.out.amax);
   else
     hipLaunchKernelGGL(dwconv3x3_strip_kernel<_Float16>, dim3(nb), dim3(256), 0, st, (const _Float16*)op.in.ptr, op.in.cs, op.in.coff,
                        grp, gstride, op.grp_off, (_Float16*)op.out.ptr, op.out.cs, op.out.coff, pc.w.as<float>(),
                        pc.bias.as<float>(), op.has_res ? (const _Float16*)op.res.ptr : nullptr, op.res.cs, op.res.coff, C, op.act,
-                       tab, op.out.lvl->n, op.out.lvl->total_px);
+                       tab, op.out.lvl->n, op.out.lvl->total_px, op.out.amax);
+  FFP_HIP(hipGetLastError());
+}
+
+namespace {
+__global__ void amax_init_kernel(unsigned* __restrict__ slots, const unsigned* __restrict__ init, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) slots[i] = init[i];
+}
+__global__ void amax_max_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src) {
+  if (threadIdx.x == 0) *dst = max(*dst, *src);
+}
+}  // namespace
+
+void launch_amax_init(unsigned* slots, const unsigned* init, int n, hipStream_t st) {
+  hipLaunchKernelGGL(amax_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, slots, init, n);
+  FFP_HIP(hipGetLastError());
+}
+
+void launch_amax_max(unsigned* dst, const unsigned* src, hipStream_t st) {
+  hipLaunchKernelGGL(amax_max_kernel, dim3(1), dim3(64), 0, st, dst, src);
   FFP_HIP(hipGetLastError());
 }
 

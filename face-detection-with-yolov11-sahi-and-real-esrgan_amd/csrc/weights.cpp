@@ -1,6 +1,9 @@
 // weights.cpp — FFPW parsing + MFMA-fragment weight packing (host side).
 #include "weights.hpp"
 
+#include <algorithm>
+#include <cmath>
+
 namespace ffp {
 
 namespace {
@@ -119,6 +122,36 @@ void pack_conv(PackedConv& pc, const std::string& name, const float* w, const fl
     FFP_HIP(hipMemcpyAsync(pc.w16.p, h16.data(), h16.size() * 2, hipMemcpyHostToDevice, st));
     FFP_HIP(hipStreamSynchronize(st));
   }
+  std::vector<float> wsc(pc.cout_pad, 1.f);           // per-output-channel power of two of the split packing
+  if (pc.split) {
+    // fp16 hi + lo keep ~22 bits of a value only while the lo part is a normal fp16 number, i.e. for |value| >= 2^-3, and fp16
+    // overflows at 65504: scale each output channel's weights so that its largest one sits in [2^13, 2^14) (an exact power of
+    // two, undone in the epilogue). Smaller weights of the channel then carry an ABSOLUTE error <= 2^-25 (fp16 subnormal
+    // spacing), 2^-38 of the channel's largest weight — below fp32's own rounding of the sum.
+    std::vector<float> inv(pc.cout_pad, 1.f);
+    for (int n = 0; n < cout; ++n) {
+      float m = 0.f;
+      for (size_t i = 0; i < (size_t)cin * taps; ++i) m = std::max(m, std::fabs(w[(size_t)n * cin * taps + i]));
+      if (m > 0.f && std::isfinite(m)) {
+        int e;
+        std::frexp(m, &e);                            // m = f * 2^e, f in [0.5, 1)  ->  m * 2^(14 - e) in [2^13, 2^14)
+        wsc[n] = std::ldexp(1.f, 14 - e);
+        inv[n] = std::ldexp(1.f, e - 14);
+      }
+    }
+    pc.oscale.alloc(inv.size() * 4);
+    FFP_HIP(hipMemcpyAsync(pc.oscale.p, inv.data(), inv.size() * 4, hipMemcpyHostToDevice, st));
+    FFP_HIP(hipStreamSynchronize(st));
+  }
+  if (cin_real == 3 && k == 3) {
+    float bound = 0.f;
+    for (int n = 0; n < cout; ++n) {
+      float sum = b ? std::fabs(b[n]) : 0.f;
+      for (size_t i = 0; i < (size_t)cin * taps; ++i) sum += std::fabs(w[(size_t)n * cin * taps + i]);
+      bound = std::max(bound, sum);
+    }
+    pc.out_bound = bound;
+  }
   const int KG = (dt == F16 || pc.split) ? 16 : 8;    // input channels per fragment group
   const int EH = KG / 2;                // elements per lane (8 halfs / 4 floats = 16 bytes)
   pc.cin_pad = (cin + KG - 1) / KG * KG;
@@ -136,7 +169,8 @@ void pack_conv(PackedConv& pc, const std::string& name, const float* w, const fl
           for (int j = 0; j < EH; ++j) {
             const int c = cg * KG + EH * (l >> 5) + j;
             float v = (n < cout && c < cin) ? w[((size_t)n * cin + c) * taps + t] : 0.f;
-            if (pc.split) {          // hi = fp16(v), lo = fp16(v - hi): hi fragment then lo fragment
+            if (pc.split) {          // hi = fp16(v * s_n), lo = fp16(v * s_n - hi): hi fragment then lo fragment
+              v *= wsc[std::min(n, pc.cout_pad - 1)];
               const _Float16 hi = (_Float16)v;
               const _Float16 lo = (_Float16)(v - (float)hi);
               std::memcpy(frag + l * 16 + j * 2, &hi, 2);

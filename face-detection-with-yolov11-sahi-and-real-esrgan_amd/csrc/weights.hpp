@@ -33,6 +33,8 @@ struct PackedConv {
   DType dt = F32;
   bool split = false;   // dt == F32 only: fragments hold fp16 hi + fp16 lo parts (2 KiB each, k-group = 16) for the X3 kernels
   DevBuf w, bias;
+  DevBuf oscale;     // split only: fp32 [cout_pad] = 1 / s_n, the inverse of the power of two each output channel's weights were scaled by
+  float out_bound = 0.f;   // image-input convs (3 real channels in [0, 1]): max over channels of sum |w| + |b| >= any |output| (SiLU / none)
   DevBuf w_direct;   // k3 convs with 3 real input channels (stem, conv_first): fp32 [tap][3][cout] for the direct kernel
   // fp16 k3 convs with cin % 32 == 0 and cout % 32 == 0 (Real-ESRGAN body): A fragments of v_mfma_f32_16x16x32_f16 for
   // conv_rows16.hip, [32-channel tile][32-channel chunk][tap][M-tile m][lane l][8 halfs]:

@@ -152,8 +152,12 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
       P.conv_flops += o.flops; P.conv_launches += 1;
     } else {
       P.input = P.alloc(P.L[0], cin0, T);
+      P.set_amax_bound(P.input, 1.0f);                 // pixels / 255
       cv("model.0.conv", P.input, x0, 2, ACT_SILU);   // reads the 4/8-channel padded image (weights zero padded at pack)
     }
+    // the image-input conv runs on the direct (VALU) kernel: its output bound is known from the weights alone (inputs in [0, 1],
+    // |SiLU(v)| <= max(|v|, 0.279)), so the first MFMA conv finds its input's exponent without a pass over the data
+    P.set_amax_bound(x0, std::max(o.pc->out_bound, 0.3f));
   }
   TView x1 = P.alloc(P.L[2], c128, T);
   cv("model.1.conv", x0, x1, 2, ACT_SILU);
@@ -208,12 +212,12 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
   const bool fold12 = fold_up && c1024 % 64 == 0, fold15 = fold_up && c512 % 64 == 0;
   if (!fold12) {
     const TView up = cat12.slice(0, c1024);
-    P.add([x10, up](hipStream_t s) { launch_upsample2x(x10, up, s); });
+    P.add([x10, up](hipStream_t s) { launch_upsample2x(x10, up, s); launch_amax_max(up.amax, x10.amax, s); });
   }
   c3k2("model.13", cat12, x13, c512, false, 0.5, fold12 ? &x10 : nullptr);
   if (!fold15) {
     const TView up = cat15.slice(0, c512);
-    P.add([x13, up](hipStream_t s) { launch_upsample2x(x13, up, s); });
+    P.add([x13, up](hipStream_t s) { launch_upsample2x(x13, up, s); launch_amax_max(up.amax, x13.amax, s); });
   }
   TView x16 = P.alloc(P.L[3], c256, T);
   c3k2("model.16", cat15, x16, c256, false, 0.5, fold15 ? &x13 : nullptr);
@@ -256,6 +260,8 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
       cv(p + ".cv4." + ls + ".2", k2, P.head[l].slice(64 + nc_, nk), 1, ACT_NONE);
     }
   }
+
+  P.add_amax_reset(st_);      // first step of every run: max-|value| slots back to their static bounds / zero
 
   // ---- anchors -----------------------------------------------------------------------------------------------------------
   P.anchor_off.assign(n + 1, 0);

@@ -146,3 +146,45 @@ def test_conv_rows_kernel_random_shapes(gpu_lib):
         ref = ref_conv(x, wt, b, 1, 1, act, up, res, 0.2, True)
         assert y.shape == ref.shape, (it, y.shape, ref.shape)
         np.testing.assert_allclose(y, ref, rtol=2e-3, atol=2e-3, err_msg=f"case {it}: n{n} {h}x{w} {cin}->{cout} act{act} up{up} res{has_res}")
+
+
+RANGE_CASES = {
+    # name: (weight out-channel scales 10^U(lo,hi), activation multiplier, per-input-channel activation scales 10^U(lo,hi))
+    "bn_folded_weights_1e-4_to_1e3": ((-4, 3), 1.0, None),
+    "saturating_activations_x3e5": (None, 3e5, None),             # |x| up to ~1.5e6: an unscaled fp16 split gives inf / NaN
+    "tiny_activations_x1e-6": (None, 1e-6, None),                 # an unscaled split keeps ~fp16 precision here
+    "activation_channels_1e-4_to_1e3": (None, 1.0, (-4, 3)),
+    "everything_at_once": ((-4, 3), 37.0, (-3, 2)),
+}
+
+
+@pytest.mark.parametrize("name", list(RANGE_CASES))
+@pytest.mark.parametrize("shape", [(2, 24, 20, 64, 64, 3, 1), (1, 16, 16, 128, 96, 1, 1), (1, 33, 31, 32, 64, 3, 2)], ids=["k3s1", "k1", "k3s2"])
+def test_f32x3_scaled_split_is_fp32_grade_over_ranges(gpu_lib, name, shape):
+    """FFP_PREC_F32X3 outside the unit-variance comfort zone: per-channel weight scales as BatchNorm folding of a trained
+    checkpoint yields them, activations beyond fp16's range and far below it. The split is SCALED — activations by a tensor-wide
+    power of two taken from the producer's max |value|, weights by a per-output-channel power of two — so the error, relative to
+    each output channel's own magnitude, has to stay at the exact-fp32 kernel's level. Reference: float64 convolution."""
+    wsc, amul, asc = RANGE_CASES[name]
+    n, h, w, cin, cout, k, stride = shape
+    rng = np.random.default_rng(abs(hash((name, shape))) % (2 ** 31))
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32) * np.float32(amul)
+    if asc is not None:
+        x *= (10.0 ** rng.uniform(asc[0], asc[1], cin)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    if wsc is not None:
+        s = (10.0 ** rng.uniform(wsc[0], wsc[1], cout)).astype(np.float32)
+        wt *= s[:, None, None, None]
+        b *= s
+    ref = F.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), stride=stride,
+                   padding=k // 2).permute(0, 2, 3, 1).numpy()
+    scale = np.abs(ref).reshape(-1, cout).max(0) + 1e-30                 # per output channel
+    errs = {}
+    for mode, prec in (("f32x3", gpu_lib.PREC_F32X3), ("f32", gpu_lib.PREC_F32)):
+        y = gpu_lib.op_conv2d(x, wt, b, stride=stride, act=0, precision=prec)
+        assert np.isfinite(y).all(), (name, mode)
+        errs[mode] = float((np.abs(y - ref).reshape(-1, cout).max(0) / scale).max())
+    # exact-fp32 MFMA is the yardstick: its only noise is the fp32 summation order (~1e-6 at these K)
+    assert errs["f32x3"] <= max(3.0 * errs["f32"], 2e-6), (name, errs)
+    assert errs["f32x3"] <= 1e-5, (name, errs)

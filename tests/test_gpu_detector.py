@@ -95,3 +95,37 @@ def test_letterbox_geometry_kat(gpu_lib):
     from oracle import ultra_post
     for (h, w, s) in [(200, 300, 256), (480, 640, 256), (333, 777, 640), (512, 512, 1024), (1080, 1920, 640)]:
         assert gpu_lib.letterbox_geometry(h, w, s) == ultra_post.letterbox_geometry(h, w, s)
+
+
+@pytest.mark.parametrize("K", [4, 11], ids=["chan_scales_2^-4..2^4", "chan_scales_2^-11..2^11"])
+def test_f32x3_detector_with_bn_fold_like_channel_scales(gpu_lib, K):
+    """The whole detector in the default arithmetic (scaled fp16 hi/lo split) on weights whose output channels carry scales
+    spanning 2^-K..2^K per layer (RMS-normalised so the network stays finite) — what BatchNorm folding of a trained checkpoint
+    produces, unlike the unit-variance synthetic weights of the other tests. Raw head outputs vs the oracle at the usual bars, and
+    against the exact-fp32 kernel's own error."""
+    from ffp_amd import synth
+    from oracle import ultra_post
+    from oracle.yolo11_ref import Yolo11PoseRef
+    W = synth.yolo11_pose_weights("n")
+    rng = np.random.default_rng(5)
+    W2 = {}
+    for n in [k[:-7] for k in W if k.endswith(".weight")]:
+        w, b = W[n + ".weight"].copy(), W[n + ".bias"].copy()
+        if not (n.startswith("model.23") and n.endswith(".2")) and w.shape[0] > 1:      # head output convs keep their meaning
+            s = 2.0 ** rng.integers(-K, K + 1, size=w.shape[0]).astype(np.float64)
+            s = (s / np.sqrt(np.mean(s ** 2))).astype(np.float32)
+            w *= s[:, None, None, None]
+            b *= s
+        W2[n + ".weight"], W2[n + ".bias"] = w, b
+    ref = Yolo11PoseRef(W2, "n")
+    frame = synth.synthetic_frame(300, 400, seed=21)
+    tiles = [(0, 0, 256, 256), (100, 30, 356, 286)]
+    outs = {m: gpu_lib.Detector(W2, arch="n", precision=p).forward_raw(frame, tiles, 256)
+            for m, p in (("f32x3", gpu_lib.PREC_F32X3), ("f32", gpu_lib.PREC_F32))}
+    for i, t in enumerate(tiles):
+        r = ref.forward(ultra_post.preprocess(frame[t[1]:t[3], t[0]:t[2]], 256))[0].numpy()
+        assert np.isfinite(outs["f32x3"][i]).all()
+        e3, e1 = np.abs(outs["f32x3"][i] - r), np.abs(outs["f32"][i] - r)
+        np.testing.assert_allclose(outs["f32x3"][i][4], r[4], atol=2e-4, rtol=0)
+        np.testing.assert_allclose(outs["f32x3"][i][:4], r[:4], atol=2e-2, rtol=0)
+        assert e3[:5].max() <= max(3 * e1[:5].max(), 5e-3), (K, e3[:5].max(), e1[:5].max())

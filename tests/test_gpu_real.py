@@ -37,7 +37,7 @@ def test_detector_on_photographs(gpu_lib, mode):
         keep = np.ones(len(exy), bool)
         if len(exy) == 300:                    # max_det cap: the last few survivors depend on sub-tolerance score differences
             keep = econf > econf.min() + 1e-3
-        m = [x for x in match_by_iou(exy, d[:, :4]) if keep[x[0]]]
+        m = [x for x in match_by_iou(exy, d[:, :4], econf, d[:, 4]) if keep[x[0]]]
         ious = np.array([x[2] for x in m])
         assert ious.min() >= 0.999, (c, ious.min())
         i = np.array([x[0] for x in m]); j = np.array([x[1] for x in m])

@@ -18,14 +18,18 @@ def psnr_u8(a: np.ndarray, b: np.ndarray) -> float:
     return float("inf") if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
 
 
-def match_by_iou(a: np.ndarray, b: np.ndarray):
-    """Greedy one-to-one matching of box sets a (n,4), b (m,4) by best IoU. Returns list of (i, j, iou)."""
+def match_by_iou(a: np.ndarray, b: np.ndarray, sa: np.ndarray = None, sb: np.ndarray = None):
+    """Greedy one-to-one matching of box sets a (n,4), b (m,4) by best IoU. Returns list of (i, j, iou).
+    With scores sa / sb, candidates whose IoU is within 1e-6 of the best are told apart by the closest score (several
+    detections can share one box after clipping to the image: their pairing is otherwise arbitrary)."""
     out, used = [], set()
     for i in range(a.shape[0]):
         ious = iou_xyxy(np.repeat(a[i:i + 1], b.shape[0], 0), b) if b.shape[0] else np.zeros(0)
-        order = np.argsort(-ious)
-        for j in order:
-            if j not in used:
-                used.add(int(j)); out.append((i, int(j), float(ious[j])))
-                break
+        free = [j for j in range(b.shape[0]) if j not in used]
+        if not free:
+            break
+        best = max(ious[j] for j in free)
+        cand = [j for j in free if ious[j] >= best - 1e-6]
+        j = cand[0] if sa is None else min(cand, key=lambda q: abs(float(sb[q]) - float(sa[i])))
+        used.add(int(j)); out.append((i, int(j), float(ious[j])))
     return out
