@@ -117,7 +117,7 @@ class Runner:
     """One configuration of the hot path: its pipeline, its resident plans, its timed loop."""
 
     def __init__(self, args, ctx, *, det_precision=None, imgsz=None, pp_type=None, class_agnostic=None, sr_sizes=None, frames_per_step=None,
-                 exchange=None, resident=None, pipe=None):
+                 exchange=None, resident=None, pipe=None, det_batch=None):
         import torch
         from ffp_amd import _lib, pipeline, synth
         self.torch, self.pipeline, self.ctx, self.args = torch, pipeline, ctx, args
@@ -131,7 +131,7 @@ class Runner:
         self.exchange = exchange or args.exchange
         self.resident = args.resident if resident is None else resident
         self.H, self.W = args.height, args.width
-        self.DB = max(1, args.det_batch_frames)
+        self.DB = max(1, det_batch or args.det_batch_frames)
         self.SB = max(1, args.sr_batch_frames)
         self.cfg = pipeline.PipeConfig(slice_h=args.slice, slice_w=args.slice, overlap=args.overlap, imgsz=self.imgsz, conf=args.conf,
                                        pp_type=self.pp_type, class_agnostic=self.class_agnostic, sr_crops=args.sr_crops)
@@ -387,7 +387,7 @@ def main():
             if not main_state.get("gathered", False):
                 sec("with_allgather", exchange="always")
             if main_r.B != 1:
-                r = sec("one_frame_across_ranks", frames_per_step=1, exchange="auto")
+                r = sec("one_frame_across_ranks", frames_per_step=1, exchange="auto", det_batch=1)      # ONE frame's 61 items over the ranks
                 secondary["one_frame_across_ranks"]["scaling"] = "strong"
         if args.imgsz != 1024:
             sec("image_size_1024_reference_default", imgsz=1024)
