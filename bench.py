@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--exchange", default="auto", choices=["auto", "always", "never"],
                     help="all-gather of the per-item detections: auto = only when a frame's items are spread over ranks")
     ap.add_argument("--resident", action="store_true", help="frames already in HBM when the timed region starts (no upload in the span)")
-    ap.add_argument("--sr-batch-frames", type=int, default=2,
+    ap.add_argument("--sr-batch-frames", type=int, default=4,
                     help="frames whose crops are enhanced together as one ragged Real-ESRGAN batch (1: per frame)")
     ap.add_argument("--det-batch-frames", type=int, default=2,
                     help="consecutive steps whose frames are detected together as one ragged batch of slices (1: per step)")

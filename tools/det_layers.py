@@ -1,0 +1,34 @@
+"""Per-layer time, algorithmic HBM bytes and achieved GB/s of the detector's convolutions for a 2-frame group (122 items).
+Usage on the GPU box: python tools/det_layers.py [--f32]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ffp_amd  # noqa
+from ffp_amd import _lib, pipeline, synth
+import torch
+
+H, W, NF = 2160, 3840, 2
+cfg = pipeline.PipeConfig(sr_crops=0)
+Wd = synth.yolo11_pose_weights("s")
+pipe = pipeline.FramePipeline(Wd, None, cfg, arch="s", det_precision=_lib.PREC_F32 if "--f32" in sys.argv else _lib.PREC_F32X3)
+frame = torch.from_numpy(np.concatenate([synth.synthetic_frame(H, W, seed=i) for i in range(NF)], 0)).cuda()
+for it in range(4):
+    pipe.det.set_profile(it == 3)
+    pipe.detect(frame, H, W, NF)
+det = pipe.det.profile_detail()
+S2 = {"model.1.conv", "model.3.conv", "model.5.conv", "model.7.conv", "model.17.conv", "model.20.conv", "model.0.conv"}
+tot_ms = tot_b = 0
+rows = []
+for x in det:
+    variant, name = x["name"].split(" ", 1)
+    w = Wd[name + ".weight"]
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    px_out = x["flops"] / (2.0 * cin * k * k * cout)
+    px_in = px_out * (4 if name in S2 else 1)
+    es = 1 if name == "model.0.conv" else 4
+    by = px_in * (3 if name == "model.0.conv" else cin) * es + px_out * cout * 4
+    rows.append((x["ms"], name, variant, cin, cout, k, by))
+    tot_ms += x["ms"]; tot_b += by
+print(f"total conv {tot_ms:.3f} ms for {NF} frames, algorithmic bytes {tot_b/1e9:.2f} GB -> {tot_b/tot_ms/1e9:.2f} TB/s average; graph-mode stage ms:", pipe.det.last_ms())
+for ms, name, variant, cin, cout, k, by in sorted(rows, reverse=True)[:40]:
+    print(f"{name:34s} {variant:22s} {cin:4d}->{cout:4d} k{k} {ms*1e3:8.1f} us {by/1e6:8.1f} MB {by/ms/1e9:6.2f} TB/s")

@@ -1,4 +1,4 @@
-"""Aggregate rocprofv3 PMC passes into HBM bytes per launch for each conv kernel variant -> profiles/r01_pmc_traffic.json.
+"""Aggregate rocprofv3 PMC passes into HBM bytes per launch for each conv kernel variant -> profiles/<round>_pmc_traffic.json (argv[3], default r02).
 
 Collection (two separate passes, counters only, as MI355X_MICROARCH.md prescribes):
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o f --output-format csv -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline
@@ -65,7 +65,7 @@ def main():
         wr = (w[v][1] / w[v][0] * 1024) if v in w and w[v][0] else 0.0
         out["kernels"][v] = {"launches": n, "avg_us": t / n, "hbm_fetch_bytes_per_launch_x2corrected": fetch, "hbm_write_bytes_per_launch": wr,
                              "symbol": sym, "hbm_bytes_per_launch": fetch + wr}
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", (sys.argv[3] if len(sys.argv) > 3 else "r02") + "_pmc_traffic.json")
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
     print("wrote", path, "with", len(out["kernels"]), "kernel variants")
