@@ -89,6 +89,9 @@ _SIGS = {
     "ffp_sr_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "ffp_sr_profile_count": (C.c_int, [C.c_void_p, _p(C.c_int32)]),
     "ffp_sr_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, _p(C.c_double), _p(C.c_float), _p(C.c_int32)]),
+    "ffp_op_conv2d_shape": (C.c_int, [C.c_int]),
+    "ffp_op_conv1x1_up2": (C.c_int, [C.c_int, C.c_int, _p(C.c_float), _p(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_float),
+                                     _p(C.c_float), C.c_int, C.c_int, _p(C.c_float)]),
     "ffp_op_conv2d_time": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, _p(C.c_float)]),
     "ffp_op_conv2d": (C.c_int, [C.c_int, C.c_int, _p(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_float), _p(C.c_float), C.c_int,
@@ -430,6 +433,23 @@ def op_conv2d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], stride: int
     _check(lib().ffp_op_conv2d(device, precision, _fp(x), n, h, wd, cin, _fp(w), _fp(bb) if bb is not None else None, cout, k, stride,
                                groups, act, int(up), _fp(rr) if rr is not None else None, res_scale, _fp(y)))
     return y
+
+
+def op_conv1x1_up2(coarse: np.ndarray, fine: np.ndarray, w: np.ndarray, b: np.ndarray, act: int = 0, precision: int = PREC_F32X3, device: int = 0) -> np.ndarray:
+    """1x1 conv over the virtual concat [nearest_x2(coarse) | fine]; coarse (n,h/2,w/2,c_up), fine (n,h,w,c_fine), w (cout, c_up+c_fine)."""
+    coarse = np.ascontiguousarray(coarse, np.float32)
+    fine = np.ascontiguousarray(fine, np.float32)
+    w = np.ascontiguousarray(w, np.float32).reshape(w.shape[0], -1)
+    b = np.ascontiguousarray(b, np.float32)
+    n, h, wd, cf = fine.shape
+    y = np.zeros((n, h, wd, w.shape[0]), np.float32)
+    _check(lib().ffp_op_conv1x1_up2(device, precision, _fp(coarse), _fp(fine), n, h, wd, coarse.shape[3], cf, _fp(w), _fp(b), w.shape[0], act, _fp(y)))
+    return y
+
+
+def op_conv2d_shape(shape: int = -1) -> None:
+    """Pin the workgroup shape of the following op_conv2d calls (tests of one kernel variant); -1 restores the automatic choice."""
+    _check(lib().ffp_op_conv2d_shape(int(shape)))
 
 
 def op_conv2d_time(n, h, w, cin, cout, k=3, stride=1, up=False, precision=PREC_F16, iters=50, dbg=0, shape=-1, device=0) -> float:

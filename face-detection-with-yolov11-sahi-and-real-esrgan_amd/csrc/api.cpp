@@ -457,6 +457,12 @@ int ffp_sr_profile_get(ffp_sr* s, int i, char* name, int cap, double* flops, flo
 }
 
 // ---- single operator (parity tests) ------------------------------------------------------------------------------------------
+static int g_op_conv_shape = -1;
+int ffp_op_conv2d_shape(int force_shape) {
+  g_op_conv_shape = force_shape;
+  return FFP_OK;
+}
+
 int ffp_op_conv2d(int device, int precision, const float* x, int n, int h, int w, int cin, const float* wt, const float* bias, int cout,
                   int k, int stride, int groups, int act, int up, const float* res, float res_scale, float* y) {
   FFP_API_BEGIN
@@ -517,6 +523,7 @@ int ffp_op_conv2d(int device, int precision, const float* x, int n, int h, int w
       ConvOp o;
       o.pc = &pc; o.in = vin; o.out = vout; o.stride = stride; o.act = act; o.up = up;
       if (res) { o.has_res1 = true; o.res1 = vres; o.s1 = res_scale; }
+      o.force_shape = g_op_conv_shape;
       launch_conv(o, st);
     }
     FFP_HIP(hipStreamSynchronize(st));
@@ -527,6 +534,57 @@ int ffp_op_conv2d(int device, int precision, const float* x, int n, int h, int w
       FFP_HIP(hipMemcpy(t.data(), dout.p, t.size() * 2, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < t.size(); ++i) y[i] = (float)t[i];
     }
+  } catch (...) {
+    (void)hipStreamDestroy(st);
+    throw;
+  }
+  (void)hipStreamDestroy(st);
+  FFP_API_END
+}
+
+int ffp_op_conv1x1_up2(int device, int precision, const float* coarse, const float* fine, int n, int h, int w, int c_up, int c_fine,
+                       const float* wt, const float* bias, int cout, int act, float* y) {
+  FFP_API_BEGIN
+  FFP_CHECK(coarse && fine && wt && y && n > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0 && c_up > 0 && c_fine > 0 && cout > 0, FFP_ERR_ARG, "conv1x1_up2: bad arguments");
+  FFP_CHECK(precision == FFP_PREC_F32 || precision == FFP_PREC_F32X3, FFP_ERR_ARG, "conv1x1_up2: fp32 precisions only");
+  int ndev = 0;
+  FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "conv1x1_up2: no HIP device %d (no CPU path)", device);
+  FFP_HIP(hipSetDevice(device));
+  conv_kernels_init();
+  hipStream_t st;
+  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  try {
+    const int cin = c_up + c_fine;
+    PackedConv pc;
+    pack_conv(pc, "op", wt, bias, cout, cin, 1, 1, F32, st, precision == FFP_PREC_F32X3);
+    FFP_CHECK(pc.cin == cin, FFP_ERR_ARG, "conv1x1_up2: channel count %d needs padding", cin);
+    Level lf, lc;
+    lf.build(std::vector<int>(n, h), std::vector<int>(n, w), st);
+    lc.build(std::vector<int>(n, h / 2), std::vector<int>(n, w / 2), st);
+    const size_t pf = (size_t)lf.total_px, pcs = (size_t)lc.total_px;
+    // the concat buffer holds the fine channels at [c_up, cin); its first c_up channels are never written (filled with NaN here:
+    // a kernel that read them would show)
+    std::vector<float> cat(pf * cin, std::nanf(""));
+    for (size_t p = 0; p < pf; ++p) std::memcpy(&cat[p * cin + c_up], fine + p * c_fine, sizeof(float) * c_fine);
+    DevBuf dcat(cat.size() * 4 + 256), dco(pcs * c_up * 4 + 256), dout(pf * cout * 4 + 256), slots(3 * sizeof(unsigned));
+    FFP_HIP(hipMemcpy(dcat.p, cat.data(), cat.size() * 4, hipMemcpyHostToDevice));
+    FFP_HIP(hipMemcpy(dco.p, coarse, pcs * c_up * 4, hipMemcpyHostToDevice));
+    float mf = 0.f, mc = 0.f;
+    for (size_t i = 0; i < pf * (size_t)c_fine; ++i) mf = std::max(mf, std::fabs(fine[i]));
+    for (size_t i = 0; i < pcs * (size_t)c_up; ++i) mc = std::max(mc, std::fabs(coarse[i]));
+    unsigned hb[3] = {0u, 0u, 0u};
+    std::memcpy(&hb[0], &mf, 4);
+    std::memcpy(&hb[1], &mc, 4);
+    FFP_HIP(hipMemcpy(slots.p, hb, sizeof(hb), hipMemcpyHostToDevice));
+    TView vin{dcat.p, F32, cin, 0, cin, &lf}, vco{dco.p, F32, c_up, 0, c_up, &lc}, vout{dout.p, F32, cout, 0, cout, &lf};
+    vin.amax = slots.as<unsigned>(); vco.amax = slots.as<unsigned>() + 1; vout.amax = slots.as<unsigned>() + 2;
+    ConvOp o;
+    o.pc = &pc; o.in = vin; o.out = vout; o.stride = 1; o.act = act;
+    o.has_up2 = true; o.up2 = vco; o.up2_c = c_up; o.up2_map = lf.up2_map(&lc, st);
+    o.force_shape = g_op_conv_shape;
+    launch_conv(o, st);
+    FFP_HIP(hipStreamSynchronize(st));
+    FFP_HIP(hipMemcpy(y, dout.p, pf * cout * 4, hipMemcpyDeviceToHost));
   } catch (...) {
     (void)hipStreamDestroy(st);
     throw;

@@ -68,6 +68,21 @@ __device__ __forceinline__ void split_scales(unsigned amax_bits, float* t, float
   *tinv = ok ? __uint_as_float((eb - 13u) << 23) : 1.f;
 }
 
+// (x0, x1) * t -> packed fp16 pair hi = RN(x * t) and packed fp16 pair lo = RN(x * t - hi), t a power of two: the operand split of
+// FFP_PREC_F32X3. v_fma_mix{lo,hi}_f16 compute an fp32 fma and round once to fp16, reading the fp16 third operand in place: two
+// instructions per value, against four for multiply / convert / convert back / subtract / convert. Bit-identical to
+//   hi = (_Float16)(x * t); lo = (_Float16)fmaf(x, t, -(float)hi)
+// on every input (tools/mix_split_check.hip compares 50 M values over all exponents, fp16 overflow and subnormal results).
+__device__ __forceinline__ void split_pair(float x0, float x1, float t, unsigned& hi, unsigned& lo) {
+  unsigned h, l;                        // mixlo leaves the upper half of its destination as it was; mixhi then writes it
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(t));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(t));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(t), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(t), "v"(h));
+  hi = h;
+  lo = l;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   // SiLU with the hardware exp2 / rcp (1 ulp each): ~6 VALU ops instead of ~25 for expf + IEEE divide; the epilogue of a
   // 256 px x 64 ch block otherwise spends ~2.7 us in the activation alone
@@ -87,5 +102,10 @@ bool conv_rows16_eligible(const ConvOp& op, const ConvArgs& a);
 void launch_conv_rows16(ConvArgs& a, const PackedConv& pc, Level* out_lvl, hipStream_t st);
 void conv_rows16_init();
 bool conv_rows16_enabled();     // FFP_ROWS16=0 keeps the first-generation kernel (A/B aid)
+// 1x1 fp32-split convs without LDS staging of the activations (conv_pw.hip): bit s of the mask = force_shape s (10..15) can run this op
+unsigned conv_pw_mask(const ConvOp& op, const ConvArgs& a);
+void launch_conv_pw(ConvArgs& a, int shape, hipStream_t st);
+void conv_pw_init();
+bool conv_pw_enabled();         // FFP_PW=0 keeps the tuner to the generic shapes (A/B aid)
 
 }  // namespace ffp

@@ -284,14 +284,12 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
       const int idx = tid + i * 256;
       if (idx < G::NVI) {
         if (SPLIT) {   // 4 floats -> 4 fp16 hi parts + 4 fp16 residuals, stored in the hi / lo halves of the pixel record
-          const float f[4] = {__uint_as_float(qi[i].x) * tscale, __uint_as_float(qi[i].y) * tscale, __uint_as_float(qi[i].z) * tscale,
-                              __uint_as_float(qi[i].w) * tscale};
-          union { uint2 u; _Float16 h[4]; } hi, lo;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { hi.h[q] = (_Float16)f[q]; lo.h[q] = (_Float16)(f[q] - (float)hi.h[q]); }
+          uint2 hi, lo;
+          split_pair(__uint_as_float(qi[i].x), __uint_as_float(qi[i].y), tscale, hi.x, lo.x);
+          split_pair(__uint_as_float(qi[i].z), __uint_as_float(qi[i].w), tscale, hi.y, lo.y);
           unsigned char* rec = buf + (idx / VPP) * PS + (idx % VPP) * 8;
-          *reinterpret_cast<uint2*>(rec) = hi.u;
-          *reinterpret_cast<uint2*>(rec + KC * 2) = lo.u;
+          *reinterpret_cast<uint2*>(rec) = hi;
+          *reinterpret_cast<uint2*>(rec + KC * 2) = lo;
         } else {
           *reinterpret_cast<uint4*>(buf + (idx / VPP) * PS + (idx % VPP) * 16) = qi[i];
         }
@@ -738,6 +736,7 @@ void conv_kernels_init() {
   if (done) return;
   conv_rows_init();
   conv_rows16_init();
+  conv_pw_init();
   Family<float, 1, 1>::init(); Family<float, 3, 1>::init(); Family<float, 3, 2>::init();
   Family<_Float16, 1, 1>::init(); Family<_Float16, 3, 1>::init(); Family<_Float16, 3, 2>::init();
   Family<X3, 1, 1>::init(); Family<X3, 3, 1>::init(); Family<X3, 3, 2>::init();
@@ -818,6 +817,11 @@ bool conv_rows16_enabled() {
   return on;
 }
 
+bool conv_pw_enabled() {
+  static const bool on = [] { const char* e = getenv("FFP_PW"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 static bool use_rows16(const ConvOp& op, const ConvArgs& a) {
   if (!conv_rows16_eligible(op, a)) return false;
   return a.force_shape == 9 || (a.force_shape < 0 && conv_rows16_enabled());
@@ -829,6 +833,12 @@ void launch_conv(const ConvOp& op, hipStream_t st) {
   ConvArgs a = make_conv_args(op);
   if (use_rows16(op, a)) { launch_conv_rows16(a, pc, op.out.lvl, st); FFP_HIP(hipGetLastError()); return; }
   if (conv_rows_eligible(op, a)) { launch_conv_rows(a, op.out.lvl, st); FFP_HIP(hipGetLastError()); return; }
+  if (a.force_shape >= 10 && a.force_shape <= 15) {      // pointwise kernels (conv_pw.hip): only ever picked by measurement (conv_tune) or by hand
+    FFP_CHECK(conv_pw_mask(op, a) & (1u << a.force_shape), FFP_ERR_ARG, "conv %s: pointwise shape %d cannot run this op", pc.name.c_str(), a.force_shape);
+    launch_conv_pw(a, a.force_shape, st);
+    FFP_HIP(hipGetLastError());
+    return;
+  }
   if (pc.dt == F16) launch_t<_Float16>(a, pc.k, op.stride, op.out.lvl, st);
   else if (pc.split) launch_t<X3>(a, pc.k, op.stride, op.out.lvl, st);
   else launch_t<float>(a, pc.k, op.stride, op.out.lvl, st);
@@ -840,7 +850,8 @@ int conv_tune(const ConvOp& op, hipStream_t st) {
   if (conv_direct_eligible(op)) return -1;
   const ConvArgs a = make_conv_args(op);
   if (use_rows16(op, a) || conv_rows_eligible(op, a)) return -1;
-  const unsigned mask = pc.dt == F16 ? valid_t<_Float16>(a, pc.k, op.stride) : pc.split ? valid_t<X3>(a, pc.k, op.stride) : valid_t<float>(a, pc.k, op.stride);
+  const unsigned mask = (pc.dt == F16 ? valid_t<_Float16>(a, pc.k, op.stride) : pc.split ? valid_t<X3>(a, pc.k, op.stride) : valid_t<float>(a, pc.k, op.stride)) |
+                        (conv_pw_enabled() ? conv_pw_mask(op, a) : 0u);
   if (__builtin_popcount(mask) < 2) return -1;
   const int heur = pc.dt == F16 ? choose_t<_Float16>(a, pc.k, op.stride, op.out.lvl)
                    : pc.split ? choose_t<X3>(a, pc.k, op.stride, op.out.lvl) : choose_t<float>(a, pc.k, op.stride, op.out.lvl);
@@ -860,7 +871,7 @@ int conv_tune(const ConvOp& op, hipStream_t st) {
   };
   float best_t = 0.f, heur_t = 0.f;
   int best = -1;
-  for (int shape = 0; shape < 6; ++shape) {
+  for (int shape = 0; shape < 16; ++shape) {
     if (!(mask & (1u << shape))) continue;
     const float t1 = time_shape(shape, 2);                              // also builds the shape's tile table
     const int iters = std::min(24, std::max(3, (int)(300.f / std::max(t1, 1.f))));
@@ -881,6 +892,10 @@ std::string conv_variant(const ConvOp& op) {
   const ConvArgs a = make_conv_args(op);
   if (use_rows16(op, a)) return "f16_k3s1_rows16";
   if (conv_rows_eligible(op, a)) return "f16_k3s1_rows";
+  if (op.force_shape >= 10 && op.force_shape <= 15) {
+    static const char* pw[6] = {"f32x3_k1s1_pw1x4", "f32x3_k1s1_pw2x2", "f32x3_k1s1_pw2x1", "f32x3_k1s1_pw1x4w", "f32x3_k1s1_pw2x2w", "f32x3_k1s1_pw2x1w"};
+    return pw[op.force_shape - 10];
+  }
   const int shape = (op.force_shape >= 0 && op.force_shape < 6) ? op.force_shape
                     : pc.dt == F16 ? choose_t<_Float16>(a, pc.k, op.stride, op.out.lvl)
                     : pc.split ? choose_t<X3>(a, pc.k, op.stride, op.out.lvl) : choose_t<float>(a, pc.k, op.stride, op.out.lvl);

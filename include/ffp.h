@@ -216,6 +216,18 @@ int ffp_op_conv2d(int device, int precision, const float* x, int n, int h, int w
                   const float* bias, int cout, int k, int stride, int groups, int act, int up, const float* res,
                   float res_scale, float* y);
 
+/* 1x1 conv over the virtual concat [nearest_x2(coarse) | fine] (the YOLO neck's Upsample + Concat + C3k2.cv1 without
+ * materialising the upsampled tensor: /root/reference's model graph via ultralytics' yolo11-pose.yaml layers 11-13 and 14-16).
+ * coarse: [n][h/2][w/2][c_up] (c_up a multiple of 64), fine: [n][h][w][c_fine]; wt: [cout][c_up + c_fine] (input channel
+ * order = concat order); y = act(conv + bias): [n][h][w][cout]. fp32 and fp32-split precisions. */
+int ffp_op_conv1x1_up2(int device, int precision, const float* coarse, const float* fine, int n, int h, int w, int c_up, int c_fine,
+                       const float* wt, const float* bias, int cout, int act, float* y);
+
+/* Tuning / test hook: pin the workgroup shape ffp_op_conv2d uses from now on (process-wide; -1 = automatic, the default).
+ * 0..5 generic shapes, 9 conv_rows16, 10..12 the pointwise kernels of conv_pw.hip. A shape that cannot run the op is an error
+ * of the following ffp_op_conv2d call. */
+int ffp_op_conv2d_shape(int force_shape);
+
 /* Tuning hook: mean device time (HIP events, microseconds) of `iters` back-to-back launches of one dense convolution on
  * synthetic data. dbg_mask skips kernel phases (1 stores, 2 MFMAs, 4 chunk refetch, 8 LDS stash) to attribute time —
  * results are then wrong by construction; force_shape pins the workgroup shape (-1: automatic). */

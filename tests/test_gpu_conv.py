@@ -188,3 +188,105 @@ def test_f32x3_scaled_split_is_fp32_grade_over_ranges(gpu_lib, name, shape):
     # exact-fp32 MFMA is the yardstick: its only noise is the fp32 summation order (~1e-6 at these K)
     assert errs["f32x3"] <= max(3.0 * errs["f32"], 2e-6), (name, errs)
     assert errs["f32x3"] <= 1e-5, (name, errs)
+
+
+PW_SHAPES = {10: (4, 40), 11: (2, 40), 12: (1, 40), 13: (4, 80), 14: (2, 80), 15: (1, 80)}      # force_shape -> (32-channel tiles per workgroup, LDS fragments)
+
+
+def pw_can_run(shape, cin, cout):
+    nt, frags = PW_SHAPES[shape]
+    return cin % 32 == 0 and (-(-cout // 32)) % nt == 0 and nt * (cin // 16) <= frags
+
+
+PW_CASES = [
+    # (n, h, w, cin, cout, act)
+    (2, 16, 16, 64, 128, 1),
+    (1, 33, 47, 96, 128, 1),        # 1551 pixels: ragged last pixel block
+    (1, 16, 16, 128, 1, 0),         # one out channel (cls head)
+    (1, 20, 24, 32, 15, 0),         # cout not a multiple of 4 (keypoint head): dword stores, channel tail by the range check
+    (1, 64, 64, 192, 256, 1),
+    (2, 40, 40, 64, 64, 1),
+    (3, 9, 16, 512, 512, 1),
+    (1, 16, 16, 256, 256, 0),
+    (5, 128, 128, 96, 128, 1),      # 81920 pixels: every workgroup walks several pixel blocks with resident weights
+    (9, 96, 96, 64, 64, 1),
+    (2, 32, 32, 1024, 512, 1),      # K = 1024: one 32-channel tile per 8-wave workgroup is all that stays resident
+    (9, 64, 64, 384, 128, 1),
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=lambda c: "n%d_%dx%d_c%d-%d_a%d" % c)
+def test_conv_pointwise_kernels(gpu_lib, case):
+    """conv_pw.hip (1x1, fp32-grade split, activations loaded straight into MFMA operand registers): every workgroup shape
+    that can run the case, against the fp32 reference at the generic split kernel's tolerance, and against the generic kernel
+    itself (same products, same accumulation order inside a k-group: 1e-6 of the output scale)."""
+    n, h, w, cin, cout, act = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, cin, 1, 1), dtype=np.float32) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout, dtype=np.float32) * 0.1
+    ref = ref_conv(x, wt, b, 1, 1, act, 0, None, 1.0, False)
+    gen = gpu_lib.op_conv2d(x, wt, b, act=act, precision=gpu_lib.PREC_F32X3)
+    ran = 0
+    try:
+        for shape in sorted(PW_SHAPES):
+            if not pw_can_run(shape, cin, cout):
+                continue
+            gpu_lib.op_conv2d_shape(shape)
+            y = gpu_lib.op_conv2d(x, wt, b, act=act, precision=gpu_lib.PREC_F32X3)
+            np.testing.assert_allclose(y, ref, rtol=3e-5, atol=3e-5, err_msg=f"shape {shape}")
+            np.testing.assert_allclose(y, gen, rtol=0, atol=2e-6 * max(1.0, float(np.abs(ref).max())), err_msg=f"shape {shape} vs generic")
+            ran += 1
+    finally:
+        gpu_lib.op_conv2d_shape(-1)
+    assert ran >= 1
+
+
+def test_conv_pointwise_input_and_output_views_ranges(gpu_lib):
+    """Scaled split through the pointwise kernels: per-channel weight scales over 1e-4..1e3 and activations near the fp16
+    limits stay fp32-grade (same bar as the generic kernel's range test)."""
+    rng = np.random.default_rng(5)
+    cin, cout = 96, 128
+    x = (rng.standard_normal((2, 24, 24, cin)) * 3000.0).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32) * (10.0 ** rng.uniform(-4, 3, (cout, 1, 1, 1))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = ref_conv(x.astype(np.float64).astype(np.float32), wt, b, 1, 1, 0, 0, None, 1.0, False)
+    ref64 = np.einsum("nhwc,oc->nhwo", x.astype(np.float64), wt[:, :, 0, 0].astype(np.float64)) + b
+    scale = np.abs(ref64).max(axis=(0, 1, 2), keepdims=True)
+    try:
+        for shape in (10, 11, 13, 14):
+            gpu_lib.op_conv2d_shape(shape)
+            y = gpu_lib.op_conv2d(x, wt, b, act=0, precision=gpu_lib.PREC_F32X3)
+            assert np.abs((y - ref64) / scale).max() <= 2.0 * max(np.abs((ref - ref64) / scale).max(), 1e-6)
+    finally:
+        gpu_lib.op_conv2d_shape(-1)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 256, 256, 128, 1), (1, 24, 40, 512, 256, 256, 1), (3, 34, 18, 64, 32, 64, 0), (2, 64, 64, 128, 64, 128, 1)],
+                         ids=lambda c: "n%d_%dx%d_up%d+%d-%d_a%d" % c)
+def test_conv1x1_over_virtual_upsample_concat(gpu_lib, case):
+    """1x1 conv over [nearest_x2(coarse) | fine] (YOLO neck, layers 11-13 / 14-16 of yolo11-pose.yaml) without the upsampled
+    tensor: generic kernel and every pointwise shape that can run the case, against torch (interpolate + cat + conv2d)."""
+    n, h, w, c_up, c_fine, cout, act = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    coarse = rng.standard_normal((n, h // 2, w // 2, c_up), dtype=np.float32) * 3.0
+    fine = rng.standard_normal((n, h, w, c_fine), dtype=np.float32)
+    cin = c_up + c_fine
+    wt = (rng.standard_normal((cout, cin), dtype=np.float32) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout, dtype=np.float32) * 0.1
+    up = F.interpolate(torch.from_numpy(coarse).permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+    xt = torch.cat([up, torch.from_numpy(fine).permute(0, 3, 1, 2)], 1)
+    ref = ACTS[act](F.conv2d(xt, torch.from_numpy(wt)[:, :, None, None], torch.from_numpy(b))).permute(0, 2, 3, 1).numpy()
+    tol = 3e-5 * max(1.0, float(np.abs(ref).max()))
+    ran = []
+    try:
+        for shape in [-1] + sorted(PW_SHAPES):
+            if shape >= 0 and not pw_can_run(shape, cin, cout):
+                continue
+            gpu_lib.op_conv2d_shape(shape)
+            y = gpu_lib.op_conv1x1_up2(coarse, fine, wt, b, act=act, precision=gpu_lib.PREC_F32X3)
+            np.testing.assert_allclose(y, ref, rtol=3e-5, atol=tol, err_msg=f"shape {shape}")
+            ran.append(shape)
+    finally:
+        gpu_lib.op_conv2d_shape(-1)
+    assert len(ran) >= 2, ran
