@@ -89,6 +89,9 @@ _SIGS = {
     "ffp_sr_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "ffp_sr_profile_count": (C.c_int, [C.c_void_p, _p(C.c_int32)]),
     "ffp_sr_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, _p(C.c_double), _p(C.c_float), _p(C.c_int32)]),
+    "ffp_eval_wider_pr": (C.c_int, [C.c_int, _p(C.c_double), _p(C.c_int64), _p(C.c_double), _p(C.c_int64), _p(C.c_uint8), C.c_int, C.c_double, C.c_int,
+                                    _p(C.c_int64)]),
+    "ffp_eval_dual_match": (C.c_int, [C.c_int, _p(C.c_double), _p(C.c_int64), _p(C.c_double), _p(C.c_int64), _p(C.c_uint8), C.c_int, C.c_double, _p(C.c_int32)]),
     "ffp_op_conv2d_shape": (C.c_int, [C.c_int]),
     "ffp_op_conv1x1_up2": (C.c_int, [C.c_int, C.c_int, _p(C.c_float), _p(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_float),
                                      _p(C.c_float), C.c_int, C.c_int, _p(C.c_float)]),
@@ -433,6 +436,43 @@ def op_conv2d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], stride: int
     _check(lib().ffp_op_conv2d(device, precision, _fp(x), n, h, wd, cin, _fp(w), _fp(bb) if bb is not None else None, cout, k, stride,
                                groups, act, int(up), _fp(rr) if rr is not None else None, res_scale, _fp(y)))
     return y
+
+
+def _ragged(rows, width, dtype):
+    """list of [n_i][width] arrays -> (contiguous [sum n][width], int64 offsets [len + 1])"""
+    rows = [np.asarray(r, dtype).reshape(-1, width) for r in rows]
+    off = np.zeros(len(rows) + 1, np.int64)
+    np.cumsum([len(r) for r in rows], out=off[1:])
+    flat = np.ascontiguousarray(np.concatenate(rows + [np.zeros((0, width), dtype)], 0))
+    return flat, off
+
+
+def eval_wider_pr(preds, gts, evaluate, iou_thr: float = 0.5, thresh_num: int = 1000, device: int = 0) -> np.ndarray:
+    """Official WIDER FACE protocol on the device (ffp_eval_wider_pr): per-image lists preds [N_i][5] (x, y, w, h, score), gts [G_i][4],
+    evaluate [G_i] (1 = evaluated face). -> int64 [thresh_num][2] = {valid proposals, matched faces} per score threshold."""
+    p, po = _ragged(preds, 5, np.float64)
+    g, go = _ragged(gts, 4, np.float64)
+    e, eo = _ragged([np.asarray(x, np.uint8).reshape(-1, 1) for x in evaluate], 1, np.uint8)
+    if len(po) != len(go) or not np.array_equal(go, eo):
+        raise ValueError("preds / gts / evaluate must describe the same images and faces")
+    out = np.zeros((thresh_num, 2), np.int64)
+    _check(lib().ffp_eval_wider_pr(device, p.ctypes.data_as(_p(C.c_double)), po.ctypes.data_as(_p(C.c_int64)), g.ctypes.data_as(_p(C.c_double)),
+                                   go.ctypes.data_as(_p(C.c_int64)), e.ctypes.data_as(_p(C.c_uint8)), len(po) - 1, iou_thr, thresh_num,
+                                   out.ctypes.data_as(_p(C.c_int64))))
+    return out
+
+
+def eval_dual_match(preds, faces, valid, iou_thr: float = 0.5, device: int = 0):
+    """Dual-protocol matching on the device (ffp_eval_dual_match). -> list of int32 flag arrays per image (1 TP, 0 FP, 2 not counted)."""
+    p, po = _ragged(preds, 5, np.float64)
+    f, fo = _ragged(faces, 4, np.float64)
+    v, vo = _ragged([np.asarray(x, np.uint8).reshape(-1, 1) for x in valid], 1, np.uint8)
+    if len(po) != len(fo) or not np.array_equal(fo, vo):
+        raise ValueError("preds / faces / valid must describe the same images and faces")
+    flags = np.zeros(max(int(po[-1]), 1), np.int32)
+    _check(lib().ffp_eval_dual_match(device, p.ctypes.data_as(_p(C.c_double)), po.ctypes.data_as(_p(C.c_int64)), f.ctypes.data_as(_p(C.c_double)),
+                                     fo.ctypes.data_as(_p(C.c_int64)), v.ctypes.data_as(_p(C.c_uint8)), len(po) - 1, iou_thr, flags.ctypes.data_as(_p(C.c_int32))))
+    return [flags[po[i]:po[i + 1]] for i in range(len(po) - 1)]
 
 
 def op_conv1x1_up2(coarse: np.ndarray, fine: np.ndarray, w: np.ndarray, b: np.ndarray, act: int = 0, precision: int = PREC_F32X3, device: int = 0) -> np.ndarray:

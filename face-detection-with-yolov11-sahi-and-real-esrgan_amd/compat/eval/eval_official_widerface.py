@@ -1,0 +1,131 @@
+"""eval.eval_official_widerface with the reference's surface (/root/reference/eval/eval_official_widerface.py:44-494): the official
+WIDER FACE protocol (easy / medium / hard AP from the .mat ground truth). The per-image matching and the per-threshold PR counts —
+`_image_eval` :302-347 + `_img_pr_info` :349-375, the O(images x predictions x faces) part, including the `bbox_overlaps` the reference
+imports from a Cython extension (:24-33) — run in ONE launch on the GPU (ffp_eval_wider_pr); `_dataset_pr_info` and `_voc_ap` are the
+reference's few numpy lines on the resulting integer counts. Inference (`_run_single_inference` :185-255) goes through this build's
+`utils.yolo_wrapper` / `sahi.predict` shims; predictions can also be handed in (`run(all_predictions=...)`), which is how the tests
+drive it (no WIDER FACE data or trained weights exist on the build machine). Plots (matplotlib) are left to the caller.
+"""
+from collections import defaultdict
+from pathlib import Path
+
+import numpy as np
+
+from ffp_amd import _lib
+
+
+class OfficialWiderFaceEvaluator:
+    def __init__(self, gt_path="data/dataset/widerface/wider_face_split", images_path="data/dataset/widerface/WIDER_val/images",
+                 model_path="models/yolo11s-pose-default/yolo11s_pose/weights/best.pt", device="cuda:0", use_sahi=True, slicing_strategy="uniform",
+                 use_enhancer=False, bounded_enhancement=False, face_size_threshold=50, load_model=True):
+        self.gt_path, self.images_path = Path(gt_path), Path(images_path)
+        self.settings = ["easy", "medium", "hard"]
+        self.iou_threshold = 0.5
+        self.thresh_num = 1000
+        self.use_sahi, self.slicing_strategy = use_sahi, slicing_strategy
+        self.use_enhancer, self.bounded_enhancement, self.face_size_threshold = use_enhancer, bounded_enhancement, face_size_threshold
+        self.inference_confidence = 0.01
+        self.sahi_config = {"slice_height": 640, "slice_width": 640, "overlap_ratio": 0.2} if slicing_strategy == "uniform" else {"overlap_ratio": 0.2}
+        if use_enhancer:
+            raise NotImplementedError("enhance-first evaluation modes: run FramePipeline.enhance_first and pass the predictions to run()")
+        self.detection_model = None
+        if load_model:
+            from utils.yolo_wrapper import YOLOv11PoseDetectionModel
+            self.detection_model = YOLOv11PoseDetectionModel(model_path=model_path, confidence_threshold=self.inference_confidence, device=device, load_at_init=True)
+        self._build_mode_string()
+        self._load_official_ground_truth()
+
+    def _build_mode_string(self):
+        self.mode_string = f"SAHI ({self.slicing_strategy})" if self.use_sahi else "BASELINE"
+
+    def _load_official_ground_truth(self):
+        from scipy.io import loadmat
+        gt_mat = loadmat(self.gt_path / "wider_face_val.mat")
+        self.facebox_list, self.event_list, self.file_list = gt_mat["face_bbx_list"], gt_mat["event_list"], gt_mat["file_list"]
+        self.setting_gts = {s: loadmat(self.gt_path / f"wider_{s}_val.mat")["gt_list"] for s in self.settings}
+
+    # ---- inference (:185-281), SAHI or plain predict; boxes as x, y, w, h, score -------------------------------------------------
+    def _run_single_inference(self, img_path):
+        from PIL import Image
+        img = np.asarray(Image.open(img_path).convert("RGB"))
+        if self.use_sahi:
+            from sahi.predict import get_sliced_prediction
+            cfg = dict(self.sahi_config)
+            if "slice_height" not in cfg:
+                raise NotImplementedError("adaptive slicing needs the reference's size heuristic; use slicing_strategy='uniform'")
+            res = get_sliced_prediction(img, self.detection_model, slice_height=cfg["slice_height"], slice_width=cfg["slice_width"],
+                                        overlap_height_ratio=cfg["overlap_ratio"], overlap_width_ratio=cfg["overlap_ratio"], postprocess_type="NMS", verbose=0)
+            rows = [[*p.bbox.to_xywh(), p.score.value] for p in res.object_prediction_list]
+        else:
+            self.detection_model.perform_inference(img)
+            self.detection_model.convert_original_predictions(shift_amount=[0, 0], full_shape=list(img.shape[:2]))
+            rows = [[*p.bbox.to_xywh(), p.score.value] for p in self.detection_model.object_prediction_list]
+        return np.asarray(rows, np.float64).reshape(-1, 5) if rows else np.array([])
+
+    def _run_inference_on_all_images(self):
+        predictions = defaultdict(dict)
+        for i, event in enumerate(self.event_list):
+            event_name = event[0][0]
+            for img_file in self.file_list[i][0]:
+                img_name = img_file[0][0]
+                p = self.images_path / event_name / f"{img_name}.jpg"
+                if p.exists():
+                    predictions[event_name][img_name] = self._run_single_inference(str(p))
+        return predictions
+
+    # ---- evaluation --------------------------------------------------------------------------------------------------------------
+    def _voc_ap(self, rec, prec):
+        mrec = np.concatenate(([0.], rec, [1.]))
+        mpre = np.concatenate(([0.], prec, [0.]))
+        for i in range(mpre.size - 1, 0, -1):
+            mpre[i - 1] = np.maximum(mpre[i - 1], mpre[i])
+        i = np.where(mrec[1:] != mrec[:-1])[0]
+        return np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
+
+    def _dataset_pr_info(self, pr_curve, count_face):
+        out = np.zeros((self.thresh_num, 2))
+        nz = pr_curve[:, 0] != 0
+        out[nz, 0] = pr_curve[nz, 1] / pr_curve[nz, 0]
+        out[:, 1] = pr_curve[:, 1] / count_face
+        return out
+
+    def _flatten(self, setting, all_predictions):
+        """The reference's nested loops (:404-431) as three per-image lists + the face count of the setting."""
+        gt_list = self.setting_gts[setting]
+        preds, gts, evaluate, count_face = [], [], [], 0
+        for i in range(len(self.event_list)):
+            event_name = self.event_list[i][0][0]
+            img_list = self.file_list[i][0]
+            pred_list_event = all_predictions.get(event_name, {})
+            for j in range(len(img_list)):
+                pred_info = np.asarray(pred_list_event.get(img_list[j][0][0], np.array([])), np.float64)
+                gt_boxes = self.facebox_list[i][0][j][0].astype("float")
+                keep_index = np.asarray(gt_list[i][0][j][0]).reshape(-1).astype(np.int64)
+                count_face += len(keep_index)
+                if len(gt_boxes) == 0 or len(pred_info) == 0:
+                    continue
+                flag = np.zeros(gt_boxes.shape[0], np.uint8)
+                if len(keep_index):
+                    flag[keep_index - 1] = 1
+                preds.append(pred_info.reshape(-1, 5)); gts.append(gt_boxes.reshape(-1, 4)); evaluate.append(flag)
+        return preds, gts, evaluate, count_face
+
+    def _evaluate_setting(self, setting, all_predictions):
+        preds, gts, evaluate, count_face = self._flatten(setting, all_predictions)
+        counts = _lib.eval_wider_pr(preds, gts, evaluate, self.iou_threshold, self.thresh_num).astype(np.float64)
+        pr_curve = self._dataset_pr_info(counts, count_face)
+        propose, recall = pr_curve[:, 0], pr_curve[:, 1]
+        return self._voc_ap(recall, propose), recall, propose
+
+    def run(self, all_predictions=None):
+        if all_predictions is None:
+            all_predictions = self._run_inference_on_all_images()
+        results = {}
+        for setting in self.settings:
+            ap, _, _ = self._evaluate_setting(setting, all_predictions)
+            results[setting] = ap
+        print("\n" + "=" * 50 + f"\n📊 HASIL EVALUASI - {self.mode_string}\n" + "=" * 50)
+        for setting, ap in results.items():
+            print(f"  - {setting.capitalize():<7} AP: {ap:.4f}")
+        print("=" * 50)
+        return results

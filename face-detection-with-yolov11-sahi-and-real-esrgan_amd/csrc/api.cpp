@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 
+#include "eval.hpp"
 #include "sr_ops.hpp"
 #include "yolo11.hpp"
 
@@ -24,6 +25,16 @@ using namespace ffp;
   catch (const std::exception& e) { ffp::set_last_error(e.what()); return FFP_ERR_STATE; }
 
 namespace {
+
+template <typename T> ffp::DevBuf upload(const T* src, size_t n) {
+  ffp::DevBuf b(std::max<size_t>(n, 1) * sizeof(T));
+  if (n) FFP_HIP(hipMemcpy(b.p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return b;
+}
+void check_offsets(const int64_t* off, int n, const char* what) {
+  FFP_CHECK(off && off[0] == 0, FFP_ERR_ARG, "%s offsets must start at 0", what);
+  for (int i = 0; i < n; ++i) FFP_CHECK(off[i + 1] >= off[i], FFP_ERR_ARG, "%s offsets must not decrease (image %d)", what, i);
+}
 
 std::vector<int32_t> slice_bboxes(int H, int W, int sh, int sw, float oh, float ow) {
   // sahi.slicing.get_slice_bboxes
@@ -457,6 +468,63 @@ int ffp_sr_profile_get(ffp_sr* s, int i, char* name, int cap, double* flops, flo
 }
 
 // ---- single operator (parity tests) ------------------------------------------------------------------------------------------
+// ---- WIDER FACE evaluation -----------------------------------------------------------------------------------
+int ffp_eval_wider_pr(int device, const double* preds, const int64_t* pred_off, const double* gts, const int64_t* gt_off, const uint8_t* evaluate,
+                      int n_img, double iou_thr, int thresh_num, int64_t* out_counts) {
+  FFP_API_BEGIN
+  FFP_CHECK(n_img >= 0 && thresh_num > 0 && out_counts, FFP_ERR_ARG, "eval_wider_pr: bad arguments");
+  int ndev = 0;
+  FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "eval_wider_pr: no HIP device %d (no CPU path)", device);
+  FFP_HIP(hipSetDevice(device));
+  check_offsets(pred_off, n_img, "prediction");
+  check_offsets(gt_off, n_img, "face");
+  const int64_t np = pred_off[n_img], ng = gt_off[n_img];
+  FFP_CHECK((np == 0 || preds) && (ng == 0 || (gts && evaluate)), FFP_ERR_ARG, "eval_wider_pr: null data");
+  hipStream_t st;
+  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  try {
+    DevBuf dp = upload(preds, (size_t)np * 5), dpo = upload(pred_off, (size_t)n_img + 1), dg = upload(gts, (size_t)ng * 4), dgo = upload(gt_off, (size_t)n_img + 1),
+           de = upload(evaluate, (size_t)ng), state(sizeof(int) * (size_t)(ng + 2 * np + 1)), counts(sizeof(unsigned long long) * 2 * thresh_num);
+    launch_wider_pr(dp.as<double>(), dpo.as<long long>(), dg.as<double>(), dgo.as<long long>(), de.as<unsigned char>(), n_img, iou_thr, thresh_num,
+                    state.as<int>(), np, ng, counts.as<unsigned long long>(), st);
+    FFP_HIP(hipStreamSynchronize(st));
+    FFP_HIP(hipMemcpy(out_counts, counts.p, sizeof(int64_t) * 2 * thresh_num, hipMemcpyDeviceToHost));
+  } catch (...) {
+    (void)hipStreamDestroy(st);
+    throw;
+  }
+  (void)hipStreamDestroy(st);
+  FFP_API_END
+}
+
+int ffp_eval_dual_match(int device, const double* preds, const int64_t* pred_off, const double* faces, const int64_t* face_off, const uint8_t* valid,
+                        int n_img, double iou_thr, int32_t* out_flags) {
+  FFP_API_BEGIN
+  FFP_CHECK(n_img >= 0, FFP_ERR_ARG, "eval_dual_match: bad arguments");
+  int ndev = 0;
+  FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "eval_dual_match: no HIP device %d (no CPU path)", device);
+  FFP_HIP(hipSetDevice(device));
+  check_offsets(pred_off, n_img, "prediction");
+  check_offsets(face_off, n_img, "face");
+  const int64_t np = pred_off[n_img], nf = face_off[n_img];
+  FFP_CHECK((np == 0 || (preds && out_flags)) && (nf == 0 || (faces && valid)), FFP_ERR_ARG, "eval_dual_match: null data");
+  hipStream_t st;
+  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  try {
+    DevBuf dp = upload(preds, (size_t)np * 5), dpo = upload(pred_off, (size_t)n_img + 1), df = upload(faces, (size_t)nf * 4), dfo = upload(face_off, (size_t)n_img + 1),
+           dv = upload(valid, (size_t)nf), state(sizeof(int) * (size_t)(nf + 1)), flags(sizeof(int) * (size_t)(np + 1));
+    launch_dual_match(dp.as<double>(), dpo.as<long long>(), df.as<double>(), dfo.as<long long>(), dv.as<unsigned char>(), n_img, iou_thr, state.as<int>(), nf,
+                      flags.as<int>(), st);
+    FFP_HIP(hipStreamSynchronize(st));
+    if (np) FFP_HIP(hipMemcpy(out_flags, flags.p, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost));
+  } catch (...) {
+    (void)hipStreamDestroy(st);
+    throw;
+  }
+  (void)hipStreamDestroy(st);
+  FFP_API_END
+}
+
 static int g_op_conv_shape = -1;
 int ffp_op_conv2d_shape(int force_shape) {
   g_op_conv_shape = force_shape;

@@ -216,6 +216,27 @@ int ffp_op_conv2d(int device, int precision, const float* x, int n, int h, int w
                   const float* bias, int cout, int k, int stride, int groups, int act, int up, const float* res,
                   float res_scale, float* y);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * WIDER FACE evaluation (host arrays in, integer results out; float64 throughout like the reference's numpy code)
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* "Official" protocol: /root/reference/eval/eval_official_widerface.py:302-375 (`_image_eval` + `_img_pr_info`, with the
+ * WiderFace-Evaluation `bbox_overlaps` it imports at :24-33) for all images of one difficulty setting, summed as in
+ * `_evaluate_setting` :397-443. preds [pred_off[n_img]][5] = x, y, w, h, score in the order the caller evaluates them; gts
+ * [gt_off[n_img]][4] = x, y, w, h; evaluate[g] = 1: the setting evaluates this face (the reference's `ignore[keep_index-1] = 1`),
+ * 0: a proposal matching it is dropped. Images with no prediction or no face contribute nothing (:430-431). out_counts
+ * [thresh_num][2] = {valid proposals, matched faces} at the last prediction with score >= 1 - (t+1)/thresh_num — the
+ * reference's pr_curve before `_dataset_pr_info` (counts are integers; precision / recall / AP are the caller's three lines). */
+int ffp_eval_wider_pr(int device, const double* preds, const int64_t* pred_off, const double* gts, const int64_t* gt_off, const uint8_t* evaluate,
+                      int n_img, double iou_thr, int thresh_num, int64_t* out_counts);
+
+/* "Dual" protocol matching: /root/reference/eval/eval_dual.py:272-291 (`calculate_iou`) and :369-399 of `evaluate_single_set`.
+ * faces [face_off[n_img]][4] in annotation order, valid[f] = 1: face belongs to the evaluated category set, 0: ignored face.
+ * out_flags [pred_off[n_img]]: 1 true positive, 0 false positive, 2 not counted (overlaps an ignored face, or the image has no
+ * valid face and is skipped :354-355). */
+int ffp_eval_dual_match(int device, const double* preds, const int64_t* pred_off, const double* faces, const int64_t* face_off, const uint8_t* valid,
+                        int n_img, double iou_thr, int32_t* out_flags);
+
 /* 1x1 conv over the virtual concat [nearest_x2(coarse) | fine] (the YOLO neck's Upsample + Concat + C3k2.cv1 without
  * materialising the upsampled tensor: /root/reference's model graph via ultralytics' yolo11-pose.yaml layers 11-13 and 14-16).
  * coarse: [n][h/2][w/2][c_up] (c_up a multiple of 64), fine: [n][h][w][c_fine]; wt: [cout][c_up + c_fine] (input channel
