@@ -19,6 +19,9 @@
 #ifndef FFP_SINGLE_STAGE
 #define FFP_SINGLE_STAGE 1     // tuning switch: 0 = always double-buffer the LDS stage
 #endif
+#ifndef FFP_OCC3
+#define FFP_OCC3 1           // tuning switch: 0 = small-accumulator split shapes stay at two workgroups per CU with two LDS stages
+#endif
 #ifndef FFP_DEEP_OCC1
 #define FFP_DEEP_OCC1 0      // tuning switch: 1 = shapes whose LDS allows one workgroup per CU get 512 registers and a deeper prefetch ring (measured: no gain)
 #endif
@@ -111,7 +114,11 @@ template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int K
   // shape whose single stage still fits 80 KiB runs ONE stage (two barriers per chunk, no overlap inside the workgroup)
   // and lets the second resident workgroup fill the CU instead: with one workgroup per CU its fetch, MFMA and store
   // phases simply add up (measured on the fp32-split 3x3 stride-2 layers).
-  static constexpr int STAGES = (2 * BUF <= 80 * 1024 || BUF > 80 * 1024 || !FFP_SINGLE_STAGE) ? 2 : 1;
+  // Small-accumulator shapes (one 32-channel tile per wave) whose single stage fits a third of the LDS run THREE workgroups per CU
+  // on one stage each: their fetch, MFMA and store phases do not overlap inside a workgroup (measured: the phase times add up,
+  // profiles/r02_k3_phase_probe.txt), so residency is what overlaps them.
+  static constexpr bool OCC3 = FFP_OCC3 && NIW == 1 && MI <= 2 && 3 * BUF <= 160 * 1024 && std::is_same<T, X3>::value;
+  static constexpr int STAGES = OCC3 ? 1 : (2 * BUF <= 80 * 1024 || BUF > 80 * 1024 || !FFP_SINGLE_STAGE) ? 2 : 1;
   static constexpr int LDS = STAGES * BUF;
   static constexpr int NVI = NPIX * VPP, NVW = W_FRAGS * VPF;
   static constexpr int RI = (NVI + 255) / 256, RW = (NVW + 255) / 256;   // prefetch registers (16 B each) per thread and chunk
@@ -126,8 +133,8 @@ template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int K
   static constexpr int FRAG_REGS = 4 * (PD + 1) * FPS;
   // a shape whose LDS footprint allows one workgroup per CU anyway gets the whole 512-register file (launch bound 1 wave
   // per SIMD) and spends it on prefetch depth: with D = 1 every chunk of an HBM-fed layer exposes a full memory round trip
-  static constexpr int OCC = (LDS <= 80 * 1024 || !FFP_DEEP_OCC1) ? 2 : 1;
-  static constexpr int REG_BUDGET = OCC == 2 ? 256 : 448;
+  static constexpr int OCC = OCC3 ? 3 : (LDS <= 80 * 1024 || !FFP_DEEP_OCC1) ? 2 : 1;
+  static constexpr int REG_BUDGET = OCC == 3 ? 168 : OCC == 2 ? 256 : 448;
   static constexpr int DEPTH_RAW = (REG_BUDGET - NIW * MI * 16 - 56 - FRAG_REGS - 3 * (RI + RW)) / (4 * (RI + RW));   // accumulators, fragment ring, ~56 misc, address slots
   static constexpr int DEPTH = DEPTH_RAW < 1 ? 1 : DEPTH_RAW > 4 ? 4 : DEPTH_RAW;
   static_assert(KC % KG == 0 && WM * WN == 4, "geometry");
