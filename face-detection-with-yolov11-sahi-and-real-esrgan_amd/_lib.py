@@ -92,6 +92,8 @@ _SIGS = {
     "ffp_eval_wider_pr": (C.c_int, [C.c_int, _p(C.c_double), _p(C.c_int64), _p(C.c_double), _p(C.c_int64), _p(C.c_uint8), C.c_int, C.c_double, C.c_int,
                                     _p(C.c_int64)]),
     "ffp_eval_dual_match": (C.c_int, [C.c_int, _p(C.c_double), _p(C.c_int64), _p(C.c_double), _p(C.c_int64), _p(C.c_uint8), C.c_int, C.c_double, _p(C.c_int32)]),
+    "ffp_jpeg_encode": (C.c_int, [C.c_int, _p(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_uint8), C.c_int64, _p(C.c_int64)]),
+    "ffp_jpeg_encode_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _p(C.c_uint8), C.c_int64, _p(C.c_int64)]),
     "ffp_op_conv2d_shape": (C.c_int, [C.c_int]),
     "ffp_op_conv1x1_up2": (C.c_int, [C.c_int, C.c_int, _p(C.c_float), _p(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_float),
                                      _p(C.c_float), C.c_int, C.c_int, _p(C.c_float)]),
@@ -436,6 +438,26 @@ def op_conv2d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], stride: int
     _check(lib().ffp_op_conv2d(device, precision, _fp(x), n, h, wd, cin, _fp(w), _fp(bb) if bb is not None else None, cout, k, stride,
                                groups, act, int(up), _fp(rr) if rr is not None else None, res_scale, _fp(y)))
     return y
+
+
+def jpeg_encode(img: np.ndarray, quality: int = 95, bgr: bool = False, device: int = 0) -> bytes:
+    """Baseline JPEG file (4:2:0, what cv2.imwrite / PIL write at this quality) of an h x w x 3 uint8 image, encoded on the GPU."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    cap = 1024 + h * w * 3
+    out = np.empty(cap, np.uint8)
+    n = C.c_int64(0)
+    _check(lib().ffp_jpeg_encode(device, img.ctypes.data_as(_p(C.c_uint8)), h, w, int(bgr), quality, out.ctypes.data_as(_p(C.c_uint8)), cap, C.byref(n)))
+    return out[:n.value].tobytes()
+
+
+def jpeg_encode_dev(d_ptr: int, h: int, w: int, row_stride: int, quality: int = 95, bgr: bool = True, device: int = 0) -> bytes:
+    """Same for an image already in device memory (pointer + row pitch in bytes), e.g. one enhanced crop inside the SR output buffer."""
+    cap = 1024 + h * w * 3
+    out = np.empty(cap, np.uint8)
+    n = C.c_int64(0)
+    _check(lib().ffp_jpeg_encode_dev(device, C.c_void_p(d_ptr), h, w, row_stride, int(bgr), quality, out.ctypes.data_as(_p(C.c_uint8)), cap, C.byref(n)))
+    return out[:n.value].tobytes()
 
 
 def _ragged(rows, width, dtype):

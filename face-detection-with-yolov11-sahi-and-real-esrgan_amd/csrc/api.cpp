@@ -4,6 +4,7 @@
 #include <cmath>
 
 #include "eval.hpp"
+#include "jpeg.hpp"
 #include "sr_ops.hpp"
 #include "yolo11.hpp"
 
@@ -522,6 +523,51 @@ int ffp_eval_dual_match(int device, const double* preds, const int64_t* pred_off
     throw;
   }
   (void)hipStreamDestroy(st);
+  FFP_API_END
+}
+
+// ---- JPEG at the file boundaries -----------------------------------------------------------------------------
+int ffp_jpeg_encode_dev(int device, const uint8_t* d_img, int h, int w, int64_t row_stride, int bgr, int quality, uint8_t* out, int64_t cap, int64_t* out_size) {
+  FFP_API_BEGIN
+  FFP_CHECK(out_size, FFP_ERR_ARG, "jpeg_encode: out_size is null");
+  int ndev = 0;
+  FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "jpeg_encode: no HIP device %d (no CPU path)", device);
+  FFP_HIP(hipSetDevice(device));
+  hipStream_t st;
+  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  long long n = 0;
+  try {
+    n = jpeg_encode_device(d_img, h, w, row_stride, bgr, quality, out, cap, st);
+  } catch (...) {
+    (void)hipStreamDestroy(st);
+    throw;
+  }
+  (void)hipStreamDestroy(st);
+  *out_size = n < 0 ? -n : n;
+  FFP_CHECK(n >= 0, FFP_ERR_ARG, "jpeg_encode: output buffer too small (%lld bytes needed)", -n);
+  FFP_API_END
+}
+
+int ffp_jpeg_encode(int device, const uint8_t* img, int h, int w, int bgr, int quality, uint8_t* out, int64_t cap, int64_t* out_size) {
+  FFP_API_BEGIN
+  FFP_CHECK(img && h > 0 && w > 0 && out_size, FFP_ERR_ARG, "jpeg_encode: bad arguments");
+  int ndev = 0;
+  FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "jpeg_encode: no HIP device %d (no CPU path)", device);
+  FFP_HIP(hipSetDevice(device));
+  DevBuf d((size_t)h * w * 3);
+  FFP_HIP(hipMemcpy(d.p, img, (size_t)h * w * 3, hipMemcpyHostToDevice));
+  hipStream_t st;
+  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  long long n = 0;
+  try {
+    n = jpeg_encode_device(d.as<unsigned char>(), h, w, (long long)w * 3, bgr, quality, out, cap, st);
+  } catch (...) {
+    (void)hipStreamDestroy(st);
+    throw;
+  }
+  (void)hipStreamDestroy(st);
+  *out_size = n < 0 ? -n : n;
+  FFP_CHECK(n >= 0, FFP_ERR_ARG, "jpeg_encode: output buffer too small (%lld bytes needed)", -n);
   FFP_API_END
 }
 

@@ -237,6 +237,20 @@ int ffp_eval_wider_pr(int device, const double* preds, const int64_t* pred_off, 
 int ffp_eval_dual_match(int device, const double* preds, const int64_t* pred_off, const double* faces, const int64_t* face_off, const uint8_t* valid,
                         int n_img, double iou_thr, int32_t* out_flags);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * JPEG at the file boundaries
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* Replaces `cv2.imwrite(path, img)` / `cv2.imwrite(path, img, [cv2.IMWRITE_JPEG_QUALITY, q])` for .jpg paths
+ * (/root/reference/utils/visualization.py:218-221 crops, utils/enhancer.py:273-278 enhanced crops, quality 95): baseline JFIF,
+ * YCbCr 4:2:0, integer DCT, Annex K Huffman tables — byte-for-byte the file libjpeg-turbo (OpenCV's and Pillow's codec) writes.
+ * img: h x w x 3 uint8, bgr = 1 for OpenCV's channel order (0: RGB). out: caller's buffer of `cap` bytes; *out_size = file size
+ * (also set when cap is too small: FFP_ERR_ARG, call again). _dev: the image is already in device memory (row pitch in bytes),
+ * e.g. a crop inside the buffer ffp_sr_enhance_crops_dev filled — only the compressed bytes cross PCIe. */
+int ffp_jpeg_encode(int device, const uint8_t* img, int h, int w, int bgr, int quality, uint8_t* out, int64_t cap, int64_t* out_size);
+int ffp_jpeg_encode_dev(int device, const uint8_t* d_img, int h, int w, int64_t row_stride, int bgr, int quality, uint8_t* out, int64_t cap,
+                        int64_t* out_size);
+
 /* 1x1 conv over the virtual concat [nearest_x2(coarse) | fine] (the YOLO neck's Upsample + Concat + C3k2.cv1 without
  * materialising the upsampled tensor: /root/reference's model graph via ultralytics' yolo11-pose.yaml layers 11-13 and 14-16).
  * coarse: [n][h/2][w/2][c_up] (c_up a multiple of 64), fine: [n][h][w][c_fine]; wt: [cout][c_up + c_fine] (input channel
