@@ -94,6 +94,11 @@ _SIGS = {
     "ffp_eval_dual_match": (C.c_int, [C.c_int, _p(C.c_double), _p(C.c_int64), _p(C.c_double), _p(C.c_int64), _p(C.c_uint8), C.c_int, C.c_double, _p(C.c_int32)]),
     "ffp_jpeg_encode": (C.c_int, [C.c_int, _p(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_uint8), C.c_int64, _p(C.c_int64)]),
     "ffp_jpeg_encode_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _p(C.c_uint8), C.c_int64, _p(C.c_int64)]),
+    "ffp_jpeg_encode_batch_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_int, _p(C.c_int64), _p(C.c_int32), _p(C.c_int32), _p(C.c_int64), C.c_int, C.c_int, _p(C.c_uint8),
+                                            C.c_int64, _p(C.c_int64)]),
+    "ffp_jpeg_info": (C.c_int, [_p(C.c_uint8), C.c_int64, _p(C.c_int32), _p(C.c_int32), _p(C.c_int32)]),
+    "ffp_jpeg_decode": (C.c_int, [C.c_int, _p(C.c_uint8), C.c_int64, C.c_int, _p(C.c_uint8), C.c_int64]),
+    "ffp_jpeg_decode_dev": (C.c_int, [C.c_int, _p(C.c_uint8), C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int64]),
     "ffp_op_conv2d_shape": (C.c_int, [C.c_int]),
     "ffp_op_conv1x1_up2": (C.c_int, [C.c_int, C.c_int, _p(C.c_float), _p(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_float),
                                      _p(C.c_float), C.c_int, C.c_int, _p(C.c_float)]),
@@ -458,6 +463,44 @@ def jpeg_encode_dev(d_ptr: int, h: int, w: int, row_stride: int, quality: int = 
     n = C.c_int64(0)
     _check(lib().ffp_jpeg_encode_dev(device, C.c_void_p(d_ptr), h, w, row_stride, int(bgr), quality, out.ctypes.data_as(_p(C.c_uint8)), cap, C.byref(n)))
     return out[:n.value].tobytes()
+
+
+def jpeg_encode_batch_dev(d_base: int, offsets, hs, ws, quality: int = 95, bgr: bool = True, device: int = 0):
+    """n device-resident images (d_base + offsets[i], hs[i] x ws[i] x 3, tightly packed rows) -> list of JPEG files, one pass on the GPU."""
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    hs, ws = np.ascontiguousarray(hs, np.int32), np.ascontiguousarray(ws, np.int32)
+    n = len(offsets)
+    cap = int(1024 * n + 3 * (hs.astype(np.int64) * ws).sum())
+    out = np.empty(max(cap, 1), np.uint8)
+    oo = np.zeros(n + 1, np.int64)
+    _check(lib().ffp_jpeg_encode_batch_dev(device, C.c_void_p(d_base), n, offsets.ctypes.data_as(_p(C.c_int64)), hs.ctypes.data_as(_p(C.c_int32)),
+                                           ws.ctypes.data_as(_p(C.c_int32)), None, int(bgr), quality, out.ctypes.data_as(_p(C.c_uint8)), cap, oo.ctypes.data_as(_p(C.c_int64))))
+    return [out[oo[i]:oo[i + 1]].tobytes() for i in range(n)]
+
+
+def jpeg_info(data: bytes):
+    """(height, width, components) from the headers of a JPEG stream."""
+    buf = np.frombuffer(data, np.uint8)
+    h, w, nc = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    _check(lib().ffp_jpeg_info(buf.ctypes.data_as(_p(C.c_uint8)), len(buf), C.byref(h), C.byref(w), C.byref(nc)))
+    return h.value, w.value, nc.value
+
+
+def jpeg_decode(data: bytes, bgr: bool = False, device: int = 0) -> np.ndarray:
+    """JPEG stream -> h x w x 3 uint8 (host Huffman decoding, device IDCT / upsampling / colour conversion), what cv2.imread returns (bgr=True)."""
+    h, w, _ = jpeg_info(data)
+    buf = np.frombuffer(data, np.uint8)
+    out = np.empty((h, w, 3), np.uint8)
+    _check(lib().ffp_jpeg_decode(device, buf.ctypes.data_as(_p(C.c_uint8)), len(buf), int(bgr), out.ctypes.data_as(_p(C.c_uint8)), out.size))
+    return out
+
+
+def jpeg_decode_dev(data: bytes, d_ptr: int, row_stride: int, cap: int, bgr: bool = True, device: int = 0):
+    """Same into device memory (pointer, row pitch and capacity in bytes); returns (h, w)."""
+    h, w, _ = jpeg_info(data)
+    buf = np.frombuffer(data, np.uint8)
+    _check(lib().ffp_jpeg_decode_dev(device, buf.ctypes.data_as(_p(C.c_uint8)), len(buf), int(bgr), C.c_void_p(d_ptr), row_stride, cap))
+    return h, w
 
 
 def _ragged(rows, width, dtype):

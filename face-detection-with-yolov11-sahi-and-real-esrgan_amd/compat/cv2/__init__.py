@@ -3,6 +3,11 @@ build): the image-file calls they make — `cv2.imread` for the image size (pipe
 `cv2.imwrite` with `[cv2.IMWRITE_JPEG_QUALITY, q]` (utils/enhancer.py:273-278), `cv2.cvtColor` BGR<->RGB, `cv2.resize` —
 on Pillow + numpy, BGR arrays like OpenCV's. A real OpenCV further down sys.path always wins: this module then
 re-exports it untouched. Drawing primitives are not provided (utils.visualization of this build draws with Pillow).
+
+`.jpg` files go through this build's JPEG codec on the GPU (csrc/jpeg.hip: ffp_jpeg_decode / ffp_jpeg_encode) whenever a device is
+visible; its output is byte-identical (files) and pixel-identical (decoded arrays) to the libjpeg-turbo inside OpenCV and Pillow
+(tests/test_gpu_jpeg.py), so the choice changes the time, not one bit of the result. Files the device codec does not read
+(progressive JPEG) and machines without a GPU use Pillow, and say so once on stderr.
 """
 import importlib.machinery
 import importlib.util
@@ -37,9 +42,39 @@ else:
     COLOR_BGR2RGB, COLOR_RGB2BGR = 4, 4
     INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4 = 0, 1, 2, 3, 4
 
+    _state = {"gpu": None, "told": False}
+
+    def _gpu_codec():
+        if _state["gpu"] is None:
+            try:
+                from ffp_amd import _lib
+                _state["gpu"] = _lib if _lib.device_count() > 0 else False
+            except Exception:
+                _state["gpu"] = False
+        return _state["gpu"]
+
+    def _tell(why):
+        if not _state["told"]:
+            _state["told"] = True
+            print(f"cv2 shim: JPEG through Pillow ({why}); same bytes, host speed", file=sys.stderr)
+
+    def _is_jpeg(path):
+        return os.path.splitext(str(path))[1].lower() in (".jpg", ".jpeg")
+
     def imread(path, flags=IMREAD_COLOR):
         """HxWx3 uint8 BGR, or None when the file cannot be read (OpenCV's convention: no exception)."""
         try:
+            if _is_jpeg(path):
+                codec = _gpu_codec()
+                if codec:
+                    with open(path, "rb") as fh:
+                        data = fh.read()
+                    try:
+                        return codec.jpeg_decode(data, bgr=True)
+                    except codec.FfpError as e:               # e.g. a progressive file
+                        _tell(str(e))
+                else:
+                    _tell("no GPU visible")
             return np.asarray(Image.open(path).convert("RGB"))[..., ::-1].copy()
         except Exception:
             return None
@@ -53,8 +88,16 @@ else:
                     if k == IMWRITE_JPEG_QUALITY:
                         q = int(v)
             a = np.ascontiguousarray(img)
+            if _is_jpeg(path) and a.ndim == 3 and a.shape[2] == 3 and a.dtype == np.uint8:
+                codec = _gpu_codec()
+                if codec:
+                    data = codec.jpeg_encode(a, q, bgr=True)
+                    with open(path, "wb") as fh:
+                        fh.write(data)
+                    return True
+                _tell("no GPU visible")
             pil = Image.fromarray(a[..., ::-1] if a.ndim == 3 and a.shape[2] == 3 else a)
-            if os.path.splitext(path)[1].lower() in (".jpg", ".jpeg"):
+            if _is_jpeg(path):
                 pil.save(path, quality=q)
             else:
                 pil.save(path)

@@ -548,6 +548,33 @@ int ffp_jpeg_encode_dev(int device, const uint8_t* d_img, int h, int w, int64_t 
   FFP_API_END
 }
 
+int ffp_jpeg_encode_batch_dev(int device, const uint8_t* d_base, int n, const int64_t* offsets, const int32_t* hs, const int32_t* ws, const int64_t* strides,
+                              int bgr, int quality, uint8_t* out, int64_t cap, int64_t* out_offsets) {
+  FFP_API_BEGIN
+  FFP_CHECK(n >= 0 && out_offsets && (n == 0 || (d_base && offsets && hs && ws)), FFP_ERR_ARG, "jpeg_encode_batch: bad arguments");
+  int ndev = 0;
+  FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "jpeg_encode_batch: no HIP device %d (no CPU path)", device);
+  FFP_HIP(hipSetDevice(device));
+  std::vector<JpegSrc> src((size_t)n);
+  for (int i = 0; i < n; ++i) src[i] = JpegSrc{d_base + offsets[i], hs[i], ws[i], strides ? strides[i] : (long long)ws[i] * 3};
+  std::vector<std::vector<unsigned char>> files;
+  hipStream_t st;
+  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  try {
+    jpeg_encode_batch_device(src.data(), n, bgr, quality, files, st);
+  } catch (...) {
+    (void)hipStreamDestroy(st);
+    throw;
+  }
+  (void)hipStreamDestroy(st);
+  int64_t pos = 0;
+  for (int i = 0; i < n; ++i) { out_offsets[i] = pos; pos += (int64_t)files[i].size(); }
+  out_offsets[n] = pos;
+  FFP_CHECK(out && cap >= pos, FFP_ERR_ARG, "jpeg_encode_batch: output buffer too small (%lld bytes needed)", (long long)pos);
+  for (int i = 0; i < n; ++i) std::memcpy(out + out_offsets[i], files[i].data(), files[i].size());
+  FFP_API_END
+}
+
 int ffp_jpeg_encode(int device, const uint8_t* img, int h, int w, int bgr, int quality, uint8_t* out, int64_t cap, int64_t* out_size) {
   FFP_API_BEGIN
   FFP_CHECK(img && h > 0 && w > 0 && out_size, FFP_ERR_ARG, "jpeg_encode: bad arguments");
@@ -568,6 +595,61 @@ int ffp_jpeg_encode(int device, const uint8_t* img, int h, int w, int bgr, int q
   (void)hipStreamDestroy(st);
   *out_size = n < 0 ? -n : n;
   FFP_CHECK(n >= 0, FFP_ERR_ARG, "jpeg_encode: output buffer too small (%lld bytes needed)", -n);
+  FFP_API_END
+}
+
+int ffp_jpeg_info(const uint8_t* data, int64_t n, int32_t* out_h, int32_t* out_w, int32_t* out_ncomp) {
+  FFP_API_BEGIN
+  FFP_CHECK(data && out_h && out_w, FFP_ERR_ARG, "jpeg_info: null argument");
+  JpegScan s;
+  jpeg_entropy_decode(data, n, s, true);
+  *out_h = s.h; *out_w = s.w;
+  if (out_ncomp) *out_ncomp = s.ncomp;
+  FFP_API_END
+}
+
+int ffp_jpeg_decode_dev(int device, const uint8_t* data, int64_t n, int bgr, uint8_t* d_out, int64_t row_stride, int64_t cap) {
+  FFP_API_BEGIN
+  FFP_CHECK(data && d_out, FFP_ERR_ARG, "jpeg_decode: null argument");
+  int ndev = 0;
+  FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "jpeg_decode: no HIP device %d (no CPU path)", device);
+  FFP_HIP(hipSetDevice(device));
+  JpegScan s;
+  jpeg_entropy_decode(data, n, s, false);
+  FFP_CHECK(row_stride >= (int64_t)s.w * 3 && cap >= row_stride * (s.h - 1) + (int64_t)s.w * 3, FFP_ERR_ARG, "jpeg_decode: output buffer too small for %dx%d", s.w, s.h);
+  hipStream_t st;
+  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  try {
+    jpeg_reconstruct_device(s, d_out, row_stride, bgr, st);
+  } catch (...) {
+    (void)hipStreamDestroy(st);
+    throw;
+  }
+  (void)hipStreamDestroy(st);
+  FFP_API_END
+}
+
+int ffp_jpeg_decode(int device, const uint8_t* data, int64_t n, int bgr, uint8_t* out, int64_t cap) {
+  FFP_API_BEGIN
+  FFP_CHECK(data && out, FFP_ERR_ARG, "jpeg_decode: null argument");
+  int ndev = 0;
+  FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "jpeg_decode: no HIP device %d (no CPU path)", device);
+  FFP_HIP(hipSetDevice(device));
+  JpegScan s;
+  jpeg_entropy_decode(data, n, s, false);
+  const size_t bytes = (size_t)s.h * s.w * 3;
+  FFP_CHECK(cap >= (int64_t)bytes, FFP_ERR_ARG, "jpeg_decode: output buffer too small for %dx%d", s.w, s.h);
+  DevBuf d(bytes);
+  hipStream_t st;
+  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  try {
+    jpeg_reconstruct_device(s, d.as<unsigned char>(), (long long)s.w * 3, bgr, st);
+  } catch (...) {
+    (void)hipStreamDestroy(st);
+    throw;
+  }
+  (void)hipStreamDestroy(st);
+  FFP_HIP(hipMemcpy(out, d.p, bytes, hipMemcpyDeviceToHost));
   FFP_API_END
 }
 

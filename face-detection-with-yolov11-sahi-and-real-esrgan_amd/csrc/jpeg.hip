@@ -24,6 +24,26 @@ namespace {
 __constant__ unsigned char c_zigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                                            35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+// one image of a batch: where it is, where its MCUs / blocks / raw scan bytes start in the batch-wide arrays
+struct JpegImg {
+  const unsigned char* ptr;
+  long long stride;
+  int h, w, mcus_x;
+  int mcu_base;                 // first MCU (blocks: * 6)
+  long long raw_base;           // first byte of its unstuffed scan in the batch stream (multiple of 256), set after the length scan
+  long long bit_base;           // bit offset of its first block in the length scan, set after the scan
+  long long raw_before;         // unstuffed scan bytes of all earlier images (without the alignment gaps)
+};
+
+__device__ __forceinline__ int image_of_mcu(const JpegImg* imgs, int n_img, int mcu) {
+  int lo = 0, hi = n_img - 1;                          // last image with mcu_base <= mcu
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (imgs[mid].mcu_base <= mcu) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 struct HuffDev {              // code << 8 | length, per symbol
   unsigned dc[2][12];
   unsigned ac[2][256];
@@ -60,11 +80,16 @@ __device__ __forceinline__ void ycc(const unsigned char* px, int bgr, int& y, in
   cr = (32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16;
 }
 
-__global__ void __launch_bounds__(64) jpeg_mcu_kernel(const unsigned char* __restrict__ img, int h, int w, long long stride, int bgr, int mcus_x,
+__global__ void __launch_bounds__(64) jpeg_mcu_kernel(const JpegImg* __restrict__ imgs, int n_img, int bgr,
                                                       const unsigned short* __restrict__ qdiv /*[2][64] natural order, q*8*/, short* __restrict__ coef) {
   __shared__ int blk[6][64];
   const int lane = threadIdx.x;
-  const int mx = blockIdx.x % mcus_x, my = blockIdx.x / mcus_x;
+  const JpegImg im = imgs[image_of_mcu(imgs, n_img, blockIdx.x)];
+  const unsigned char* img = im.ptr;
+  const int h = im.h, w = im.w, mcus_x = im.mcus_x;
+  const long long stride = im.stride;
+  const int local = (int)blockIdx.x - im.mcu_base;
+  const int mx = local % mcus_x, my = local / mcus_x;
   // luma: 256 samples, edge pixels replicated
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -144,11 +169,11 @@ __global__ void __launch_bounds__(64) jpeg_mcu_kernel(const unsigned char* __res
   }
 }
 
-__device__ __forceinline__ int prev_dc(const short* coef, int blk_id) {
-  // previous block of the same component in scan order (MCU = Y Y Y Y Cb Cr)
+__device__ __forceinline__ int prev_dc(const short* coef, int blk_id, int first_mcu) {
+  // previous block of the same component in scan order (MCU = Y Y Y Y Cb Cr); predictions start at 0 in every image
   const int m = blk_id / 6, j = blk_id % 6;
   if (j >= 1 && j <= 3) return coef[(size_t)(blk_id - 1) * 64];
-  if (m == 0) return 0;
+  if (m == first_mcu) return 0;
   return coef[((size_t)(m - 1) * 6 + (j == 0 ? 3 : j)) * 64];
 }
 
@@ -178,12 +203,22 @@ template <typename F> __device__ __forceinline__ void encode_block(const short* 
   if (r > 0) { e = hd->ac[tab][0]; put(e >> 8, e & 0xFF); }
 }
 
-__global__ void jpeg_bits_kernel(const short* __restrict__ coef, int n_blocks, const HuffDev* __restrict__ hd, unsigned* __restrict__ len) {
+__global__ void jpeg_bits_kernel(const short* __restrict__ coef, int n_blocks, const JpegImg* __restrict__ imgs, int n_img, const HuffDev* __restrict__ hd,
+                                 unsigned* __restrict__ len) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_blocks) return;
+  const int first = imgs[image_of_mcu(imgs, n_img, b / 6)].mcu_base;
   unsigned n = 0;
-  encode_block(coef + (size_t)b * 64, prev_dc(coef, b), hd, b % 6 >= 4, [&](unsigned, int l) { n += l; });
+  encode_block(coef + (size_t)b * 64, prev_dc(coef, b, first), hd, b % 6 >= 4, [&](unsigned, int l) { n += l; });
   len[b] = n;
+}
+
+// bit offsets of the images' first blocks (and the grand total) out of the block scan: what the host needs to lay the streams out
+__global__ void jpeg_image_bits_kernel(const JpegImg* __restrict__ imgs, int n_img, const unsigned long long* __restrict__ off,
+                                       const unsigned long long* __restrict__ total, unsigned long long* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_img) out[i] = off[(size_t)imgs[i].mcu_base * 6];
+  if (i == n_img) out[i] = *total;
 }
 
 // two-level exclusive scan of 32-bit counts into 64-bit offsets: 1024 items per workgroup
@@ -226,11 +261,14 @@ __global__ void scan_add_kernel(unsigned long long* out, int n, const unsigned l
   if (i < n) out[i] += sums[i >> 10];
 }
 
-__global__ void jpeg_emit_kernel(const short* __restrict__ coef, int n_blocks, const HuffDev* __restrict__ hd, const unsigned long long* __restrict__ off,
-                                 const unsigned long long* __restrict__ total_bits, unsigned* __restrict__ words) {
+__global__ void jpeg_emit_kernel(const short* __restrict__ coef, int n_blocks, const JpegImg* __restrict__ imgs, int n_img, const HuffDev* __restrict__ hd,
+                                 const unsigned long long* __restrict__ off, unsigned* __restrict__ words) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_blocks) return;
-  unsigned long long pos = off[b];
+  const int ii = image_of_mcu(imgs, n_img, b / 6);
+  const JpegImg im = imgs[ii];
+  const int last_block = (ii + 1 < n_img ? imgs[ii + 1].mcu_base : n_blocks / 6) * 6 - 1;
+  unsigned long long pos = (unsigned long long)im.raw_base * 8ull + (off[b] - (unsigned long long)im.bit_base);
   auto put = [&](unsigned code, int l) {
     const unsigned long long v = (unsigned long long)code << (64 - (int)(pos & 31) - l);
     const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
@@ -238,17 +276,25 @@ __global__ void jpeg_emit_kernel(const short* __restrict__ coef, int n_blocks, c
     if (lo) atomicOr(words + (pos >> 5) + 1, __builtin_bswap32(lo));
     pos += l;
   };
-  encode_block(coef + (size_t)b * 64, prev_dc(coef, b), hd, b % 6 >= 4, put);
-  if (b == n_blocks - 1) {                             // jchuff.c flush_bits: fill the last byte with ones
-    const int rem = (int)(*total_bits & 7);
+  encode_block(coef + (size_t)b * 64, prev_dc(coef, b, im.mcu_base), hd, b % 6 >= 4, put);
+  if (b == last_block) {                               // jchuff.c flush_bits: fill the image's last byte with ones
+    const int rem = (int)(pos & 7);
     if (rem) put(0x7Fu >> (rem - 1), 8 - rem);
   }
 }
 
-__global__ void __launch_bounds__(256) stuff_count_kernel(const unsigned char* __restrict__ raw, long long n, unsigned* __restrict__ cnt) {
+// unstuffed streams: image i occupies bytes [raw_base, raw_base + raw_len) of `raw`, raw_base a multiple of 256, so that every
+// 256-byte chunk belongs to one image; chunk_img[c] = its image, the tail of an image's last chunk is not data
+__device__ __forceinline__ bool stuff_valid(const JpegImg* imgs, const int* chunk_img, const long long* raw_len, int chunk, long long i) {
+  const int ii = chunk_img[chunk];
+  return i - imgs[ii].raw_base < raw_len[ii];
+}
+
+__global__ void __launch_bounds__(256) stuff_count_kernel(const unsigned char* __restrict__ raw, const JpegImg* __restrict__ imgs, const int* __restrict__ chunk_img,
+                                                          const long long* __restrict__ raw_len, unsigned* __restrict__ cnt) {
   __shared__ unsigned s[256];
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  s[threadIdx.x] = (i < n && raw[i] == 0xFF) ? 1u : 0u;
+  s[threadIdx.x] = (stuff_valid(imgs, chunk_img, raw_len, blockIdx.x, i) && raw[i] == 0xFF) ? 1u : 0u;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
@@ -256,12 +302,14 @@ __global__ void __launch_bounds__(256) stuff_count_kernel(const unsigned char* _
   }
   if (threadIdx.x == 0) cnt[blockIdx.x] = s[0];
 }
-__global__ void __launch_bounds__(256) stuff_scatter_kernel(const unsigned char* __restrict__ raw, long long n, const unsigned long long* __restrict__ before,
+__global__ void __launch_bounds__(256) stuff_scatter_kernel(const unsigned char* __restrict__ raw, const JpegImg* __restrict__ imgs, const int* __restrict__ chunk_img,
+                                                            const long long* __restrict__ raw_len, const unsigned long long* __restrict__ before,
                                                             unsigned char* __restrict__ out) {
   __shared__ unsigned s[256];
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const unsigned char v = i < n ? raw[i] : 0;
-  const unsigned f = (i < n && v == 0xFF) ? 1u : 0u;
+  const bool ok = stuff_valid(imgs, chunk_img, raw_len, blockIdx.x, i);
+  const unsigned char v = ok ? raw[i] : 0;
+  const unsigned f = (ok && v == 0xFF) ? 1u : 0u;
   s[threadIdx.x] = f;
   __syncthreads();
   for (int o = 1; o < 256; o <<= 1) {
@@ -270,11 +318,20 @@ __global__ void __launch_bounds__(256) stuff_scatter_kernel(const unsigned char*
     s[threadIdx.x] += a;
     __syncthreads();
   }
-  if (i < n) {
-    const long long dst = i + (long long)before[blockIdx.x] + (s[threadIdx.x] - f);
+  if (ok) {                                            // compact output: earlier images' bytes + this image's bytes so far + every 0x00 inserted so far
+    const JpegImg im = imgs[chunk_img[blockIdx.x]];
+    const long long dst = im.raw_before + (i - im.raw_base) + (long long)before[blockIdx.x] + (s[threadIdx.x] - f);
     out[dst] = v;
     if (f) out[dst + 1] = 0;
   }
+}
+
+// number of 0x00 bytes inserted before each image's first chunk (and in total): with raw_before, where every stuffed stream starts
+__global__ void jpeg_image_ff_kernel(const int* __restrict__ first_chunk, int n_img, const unsigned long long* __restrict__ before, const unsigned long long* __restrict__ total,
+                                     unsigned long long* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_img) out[i] = before[first_chunk[i]];
+  if (i == n_img) out[i] = *total;
 }
 
 void derive(const unsigned char* bits, const unsigned char* vals, int nvals, unsigned* out) {
@@ -329,8 +386,8 @@ void put_seg(std::vector<unsigned char>& o, int marker, const std::vector<unsign
 }
 
 struct Workspace {
-  DevBuf coef, len, off, sums, total, words, cnt, cnt_off, cnt_sums, cnt_total, out, hd, qdiv;
-  size_t cap_blocks = 0, cap_words = 0;
+  DevBuf coef, len, off, sums, total, words, cnt, cnt_off, cnt_sums, cnt_total, out, hd, qdiv, imgs, img_vals, img_len, first_chunk, chunk_img;
+  size_t cap_blocks = 0, cap_words = 0, cap_imgs = 0;
   bool tables = false;
 };
 std::mutex g_mu;
@@ -370,8 +427,9 @@ std::vector<unsigned char> jpeg_header(int h, int w, int quality) {
   return o;
 }
 
-long long jpeg_encode_device(const unsigned char* d_img, int h, int w, long long stride, int bgr, int quality, unsigned char* out, long long cap, hipStream_t st) {
-  FFP_CHECK(d_img && h > 0 && w > 0 && h < 65536 && w < 65536 && stride >= (long long)w * 3, FFP_ERR_ARG, "jpeg: bad image geometry %dx%d", w, h);
+void jpeg_encode_batch_device(const JpegSrc* src, int n_img, int bgr, int quality, std::vector<std::vector<unsigned char>>& files, hipStream_t st) {
+  files.assign(n_img, {});
+  if (n_img == 0) return;
   int dev = 0;
   FFP_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lock(g_mu);
@@ -388,56 +446,233 @@ long long jpeg_encode_device(const unsigned char* d_img, int h, int w, long long
     ws.sums = DevBuf(sizeof(unsigned long long) * 1024); ws.cnt_sums = DevBuf(sizeof(unsigned long long) * 1024);
     ws.tables = true;
   }
-  const int mcus_x = (w + 15) / 16, mcus_y = (h + 15) / 16, n_mcu = mcus_x * mcus_y, n_blocks = n_mcu * 6;
+  std::vector<JpegImg> imgs(n_img);
+  long long n_mcu = 0;
+  for (int i = 0; i < n_img; ++i) {
+    const JpegSrc& q = src[i];
+    FFP_CHECK(q.d_img && q.h > 0 && q.w > 0 && q.h < 65536 && q.w < 65536 && q.stride >= (long long)q.w * 3, FFP_ERR_ARG, "jpeg: bad geometry of image %d (%dx%d)", i, q.w, q.h);
+    imgs[i] = JpegImg{q.d_img, q.stride, q.h, q.w, (q.w + 15) / 16, (int)n_mcu, 0, 0, 0};
+    n_mcu += (long long)((q.w + 15) / 16) * ((q.h + 15) / 16);
+    FFP_CHECK(n_mcu * 6 <= 1024 * 1024, FFP_ERR_ARG, "jpeg: batch too large for the two-level scan (%lld blocks)", n_mcu * 6);
+  }
+  const int n_blocks = (int)n_mcu * 6;
   if ((size_t)n_blocks > ws.cap_blocks) {
     ws.cap_blocks = (size_t)n_blocks * 5 / 4;
     ws.coef = DevBuf(ws.cap_blocks * 64 * sizeof(short));
     ws.len = DevBuf(ws.cap_blocks * sizeof(unsigned));
     ws.off = DevBuf(ws.cap_blocks * sizeof(unsigned long long));
   }
-  // worst case 16 + 11 bits for the DC and 63 x (16 + 10) for the ACs of a block
-  const size_t max_words = ((size_t)n_blocks * 1665 + 31) / 32 + 2;
-  if (max_words > ws.cap_words) {
-    ws.cap_words = max_words * 5 / 4;
-    ws.words = DevBuf(ws.cap_words * 4);
-    const size_t groups = (ws.cap_words * 4 + 255) / 256;
-    ws.cnt = DevBuf(groups * sizeof(unsigned));
-    ws.cnt_off = DevBuf(groups * sizeof(unsigned long long));
-    ws.out = DevBuf(ws.cap_words * 8 + 16);
+  if ((size_t)n_img + 1 > ws.cap_imgs) {
+    ws.cap_imgs = (size_t)n_img * 2 + 8;
+    ws.imgs = DevBuf(ws.cap_imgs * sizeof(JpegImg));
+    ws.img_vals = DevBuf(ws.cap_imgs * sizeof(unsigned long long));
+    ws.img_len = DevBuf(ws.cap_imgs * sizeof(long long));
+    ws.first_chunk = DevBuf(ws.cap_imgs * sizeof(int));
   }
   unsigned char ql[64], qc[64];
   quality_tables(quality, ql, qc);
   unsigned short qd[128];
   for (int i = 0; i < 64; ++i) { qd[i] = (unsigned short)(ql[i] * 8); qd[64 + i] = (unsigned short)(qc[i] * 8); }
   FFP_HIP(hipMemcpyAsync(ws.qdiv.p, qd, sizeof(qd), hipMemcpyHostToDevice, st));
-  FFP_HIP(hipStreamSynchronize(st));                   // qd lives on this stack frame
+  FFP_HIP(hipMemcpyAsync(ws.imgs.p, imgs.data(), sizeof(JpegImg) * n_img, hipMemcpyHostToDevice, st));
 
-  hipLaunchKernelGGL(jpeg_mcu_kernel, dim3(n_mcu), dim3(64), 0, st, d_img, h, w, stride, bgr, mcus_x, ws.qdiv.as<unsigned short>(), ws.coef.as<short>());
-  hipLaunchKernelGGL(jpeg_bits_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, ws.coef.as<short>(), n_blocks, ws.hd.as<HuffDev>(), ws.len.as<unsigned>());
+  hipLaunchKernelGGL(jpeg_mcu_kernel, dim3((unsigned)n_mcu), dim3(64), 0, st, ws.imgs.as<JpegImg>(), n_img, bgr, ws.qdiv.as<unsigned short>(), ws.coef.as<short>());
+  hipLaunchKernelGGL(jpeg_bits_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, ws.coef.as<short>(), n_blocks, ws.imgs.as<JpegImg>(), n_img, ws.hd.as<HuffDev>(),
+                     ws.len.as<unsigned>());
   exclusive_scan(ws.len.as<unsigned>(), n_blocks, ws.off.as<unsigned long long>(), ws.sums.as<unsigned long long>(), ws.total.as<unsigned long long>(), st);
-  unsigned long long total_bits = 0;
-  FFP_HIP(hipMemcpyAsync(&total_bits, ws.total.p, 8, hipMemcpyDeviceToHost, st));
-  FFP_HIP(hipStreamSynchronize(st));
-  const long long raw_bytes = (long long)((total_bits + 7) / 8);
-  FFP_HIP(hipMemsetAsync(ws.words.p, 0, (size_t)((raw_bytes + 3) / 4 + 1) * 4, st));
-  hipLaunchKernelGGL(jpeg_emit_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, ws.coef.as<short>(), n_blocks, ws.hd.as<HuffDev>(),
-                     ws.off.as<unsigned long long>(), ws.total.as<unsigned long long>(), ws.words.as<unsigned>());
-  const int groups = (int)((raw_bytes + 255) / 256);
-  hipLaunchKernelGGL(stuff_count_kernel, dim3(groups), dim3(256), 0, st, ws.words.as<unsigned char>(), raw_bytes, ws.cnt.as<unsigned>());
-  exclusive_scan(ws.cnt.as<unsigned>(), groups, ws.cnt_off.as<unsigned long long>(), ws.cnt_sums.as<unsigned long long>(), ws.cnt_total.as<unsigned long long>(), st);
-  hipLaunchKernelGGL(stuff_scatter_kernel, dim3(groups), dim3(256), 0, st, ws.words.as<unsigned char>(), raw_bytes, ws.cnt_off.as<unsigned long long>(),
-                     ws.out.as<unsigned char>());
-  unsigned long long n_ff = 0;
-  FFP_HIP(hipMemcpyAsync(&n_ff, ws.cnt_total.p, 8, hipMemcpyDeviceToHost, st));
-  FFP_HIP(hipStreamSynchronize(st));
+  hipLaunchKernelGGL(jpeg_image_bits_kernel, dim3((n_img + 256) / 256), dim3(256), 0, st, ws.imgs.as<JpegImg>(), n_img, ws.off.as<unsigned long long>(),
+                     ws.total.as<unsigned long long>(), ws.img_vals.as<unsigned long long>());
+  std::vector<unsigned long long> bits(n_img + 1);
+  FFP_HIP(hipMemcpyAsync(bits.data(), ws.img_vals.p, sizeof(unsigned long long) * (n_img + 1), hipMemcpyDeviceToHost, st));
+  FFP_HIP(hipStreamSynchronize(st));                   // (also: qd and imgs live on this stack frame)
+  // lay the unstuffed streams out: each image starts on a 256-byte boundary of the raw buffer
+  std::vector<long long> raw_len(n_img);
+  std::vector<int> first_chunk(n_img + 1);
+  long long raw_pos = 0, raw_sum = 0;
+  for (int i = 0; i < n_img; ++i) {
+    raw_len[i] = (long long)((bits[i + 1] - bits[i] + 7) / 8);
+    imgs[i].bit_base = (long long)bits[i];
+    imgs[i].raw_base = raw_pos;
+    imgs[i].raw_before = raw_sum;
+    first_chunk[i] = (int)(raw_pos / 256);
+    raw_pos += (raw_len[i] + 255) / 256 * 256;
+    raw_sum += raw_len[i];
+  }
+  const int n_chunks = (int)(raw_pos / 256);
+  first_chunk[n_img] = n_chunks;
+  FFP_CHECK(n_chunks <= 1024 * 1024, FFP_ERR_ARG, "jpeg: batch too large for the two-level scan (%d stream chunks)", n_chunks);
+  const size_t need_words = (size_t)raw_pos / 4 + 64;
+  if (need_words > ws.cap_words) {
+    ws.cap_words = need_words * 5 / 4;
+    ws.words = DevBuf(ws.cap_words * 4);
+    ws.cnt = DevBuf((ws.cap_words / 64 + 2) * sizeof(unsigned));
+    ws.cnt_off = DevBuf((ws.cap_words / 64 + 2) * sizeof(unsigned long long));
+    ws.chunk_img = DevBuf((ws.cap_words / 64 + 2) * sizeof(int));
+    ws.out = DevBuf(ws.cap_words * 8 + 16);
+  }
+  std::vector<int> chunk_img((size_t)std::max(n_chunks, 1));
+  for (int i = 0; i < n_img; ++i) std::fill(chunk_img.begin() + first_chunk[i], chunk_img.begin() + first_chunk[i + 1], i);
+  FFP_HIP(hipMemcpyAsync(ws.imgs.p, imgs.data(), sizeof(JpegImg) * n_img, hipMemcpyHostToDevice, st));
+  FFP_HIP(hipMemcpyAsync(ws.img_len.p, raw_len.data(), sizeof(long long) * n_img, hipMemcpyHostToDevice, st));
+  FFP_HIP(hipMemcpyAsync(ws.first_chunk.p, first_chunk.data(), sizeof(int) * (n_img + 1), hipMemcpyHostToDevice, st));
+  FFP_HIP(hipMemcpyAsync(ws.chunk_img.p, chunk_img.data(), sizeof(int) * (size_t)n_chunks, hipMemcpyHostToDevice, st));
+  FFP_HIP(hipMemsetAsync(ws.words.p, 0, (size_t)raw_pos + 64, st));
+  hipLaunchKernelGGL(jpeg_emit_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, ws.coef.as<short>(), n_blocks, ws.imgs.as<JpegImg>(), n_img, ws.hd.as<HuffDev>(),
+                     ws.off.as<unsigned long long>(), ws.words.as<unsigned>());
+  std::vector<unsigned long long> ff(n_img + 1, 0ull);
+  if (n_chunks > 0) {
+    hipLaunchKernelGGL(stuff_count_kernel, dim3(n_chunks), dim3(256), 0, st, ws.words.as<unsigned char>(), ws.imgs.as<JpegImg>(), ws.chunk_img.as<int>(), ws.img_len.as<long long>(),
+                       ws.cnt.as<unsigned>());
+    exclusive_scan(ws.cnt.as<unsigned>(), n_chunks, ws.cnt_off.as<unsigned long long>(), ws.cnt_sums.as<unsigned long long>(), ws.cnt_total.as<unsigned long long>(), st);
+    hipLaunchKernelGGL(stuff_scatter_kernel, dim3(n_chunks), dim3(256), 0, st, ws.words.as<unsigned char>(), ws.imgs.as<JpegImg>(), ws.chunk_img.as<int>(),
+                       ws.img_len.as<long long>(), ws.cnt_off.as<unsigned long long>(), ws.out.as<unsigned char>());
+    hipLaunchKernelGGL(jpeg_image_ff_kernel, dim3((n_img + 256) / 256), dim3(256), 0, st, ws.first_chunk.as<int>(), n_img, ws.cnt_off.as<unsigned long long>(),
+                       ws.cnt_total.as<unsigned long long>(), ws.img_vals.as<unsigned long long>());
+    FFP_HIP(hipMemcpyAsync(ff.data(), ws.img_vals.p, sizeof(unsigned long long) * (n_img + 1), hipMemcpyDeviceToHost, st));
+  }
+  FFP_HIP(hipStreamSynchronize(st));                   // (the host vectors above are done with, too)
   FFP_HIP(hipGetLastError());
-  const std::vector<unsigned char> head = jpeg_header(h, w, quality);
-  const long long scan_bytes = raw_bytes + (long long)n_ff, total = (long long)head.size() + scan_bytes + 2;
+  const long long stuffed_total = raw_sum + (long long)ff[n_img];
+  std::vector<unsigned char> scans((size_t)std::max<long long>(stuffed_total, 1));
+  if (stuffed_total > 0) FFP_HIP(hipMemcpy(scans.data(), ws.out.p, (size_t)stuffed_total, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n_img; ++i) {
+    const long long a = imgs[i].raw_before + (long long)ff[i], b = (i + 1 < n_img ? imgs[i + 1].raw_before : raw_sum) + (long long)ff[i + 1];
+    std::vector<unsigned char>& f = files[i];
+    f = jpeg_header(src[i].h, src[i].w, quality);
+    f.insert(f.end(), scans.begin() + a, scans.begin() + b);
+    f.push_back(0xFF); f.push_back(0xD9);
+  }
+}
+
+long long jpeg_encode_device(const unsigned char* d_img, int h, int w, long long stride, int bgr, int quality, unsigned char* out, long long cap, hipStream_t st) {
+  JpegSrc one{d_img, h, w, stride};
+  std::vector<std::vector<unsigned char>> files;
+  jpeg_encode_batch_device(&one, 1, bgr, quality, files, st);
+  const long long total = (long long)files[0].size();
   if (out == nullptr || cap < total) return -total;    // caller learns the size it needs
-  std::memcpy(out, head.data(), head.size());
-  FFP_HIP(hipMemcpy(out + head.size(), ws.out.p, (size_t)scan_bytes, hipMemcpyDeviceToHost));
-  out[total - 2] = 0xFF; out[total - 1] = 0xD9;
+  std::memcpy(out, files[0].data(), (size_t)total);
   return total;
+}
+
+}  // namespace ffp
+
+namespace ffp {
+
+// ---- decoding: everything after the entropy decoder ----------------------------------------------------------------------------------
+namespace {
+
+// jidctint.c, one 8-point pass on dequantised values; first: columns (keeps 2 fractional bits), second: rows (final scaling)
+__device__ __forceinline__ void idct8(int (&v)[8], bool first) {
+  int z2 = v[2], z3 = v[6];
+  int z1 = (z2 + z3) * 4433;
+  const int e2 = z1 - z3 * 15137, e3 = z1 + z2 * 6270;
+  const int e0 = (v[0] + v[4]) << 13, e1 = (v[0] - v[4]) << 13;
+  const int t10 = e0 + e3, t13 = e0 - e3, t11 = e1 + e2, t12 = e1 - e2;
+  int t0 = v[7], t1 = v[5], t2 = v[3], t3 = v[1];
+  z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2;
+  int z4 = t1 + t3;
+  const int z5 = (z3 + z4) * 9633;
+  t0 *= 2446; t1 *= 16819; t2 *= 25172; t3 *= 12299;
+  z1 = -z1 * 7373; z2 = -z2 * 20995; z3 = -z3 * 16069 + z5; z4 = -z4 * 3196 + z5;
+  t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+  const int n = first ? 11 : 18;
+  v[0] = descale(t10 + t3, n); v[7] = descale(t10 - t3, n);
+  v[1] = descale(t11 + t2, n); v[6] = descale(t11 - t2, n);
+  v[2] = descale(t12 + t1, n); v[5] = descale(t12 - t1, n);
+  v[3] = descale(t13 + t0, n); v[4] = descale(t13 - t0, n);
+}
+
+// 8 blocks per workgroup: lane = (block, column) in the first pass, (block, row) in the second; plane row pitch = blocks_x * 8
+__global__ void __launch_bounds__(64) jpeg_idct_kernel(const short* __restrict__ coef, int n_blocks, int blocks_x, const unsigned short* __restrict__ qt,
+                                                       unsigned char* __restrict__ plane) {
+  __shared__ int ws[8][64];
+  const int lb = threadIdx.x >> 3, idx = threadIdx.x & 7;
+  const int b = blockIdx.x * 8 + lb;
+  int v[8];
+  if (b < n_blocks) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = (int)coef[(size_t)b * 64 + r * 8 + idx] * (int)qt[r * 8 + idx];
+    idct8(v, true);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ws[lb][r * 8 + idx] = v[r];
+  }
+  __syncthreads();
+  if (b < n_blocks) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = ws[lb][idx * 8 + c];
+    idct8(v, false);
+    const int by = b / blocks_x, bx = b % blocks_x;
+    unsigned char* dst = plane + ((size_t)(by * 8 + idx) * blocks_x + bx) * 8;
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      lo |= (unsigned)min(max(v[c] + 128, 0), 255) << (8 * c);
+      hi |= (unsigned)min(max(v[4 + c] + 128, 0), 255) << (8 * c);
+    }
+    *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+  }
+}
+
+// one thread per output pixel: chroma through libjpeg's "fancy" triangle upsampling (jdsample.c; replication when the component is
+// at most 2 samples wide), then jdcolor.c YCbCr -> RGB
+__global__ void jpeg_colour_kernel(const unsigned char* __restrict__ py, const unsigned char* __restrict__ pcb, const unsigned char* __restrict__ pcr, int h, int w,
+                                   int pitch_y, int pitch_c, int ch, int cw, int hsub, int vsub, int ncomp, int bgr, long long stride, unsigned char* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const int Y = py[(size_t)y * pitch_y + x];
+  int r, g, b;
+  if (ncomp == 1) {
+    r = g = b = Y;
+  } else {
+    int cbv, crv;
+    auto up = [&](const unsigned char* p) {
+      if (hsub == 1) return (int)p[(size_t)y * pitch_c + x];
+      const int c = x >> 1;
+      if (cw <= 2) return (int)p[(size_t)(vsub == 2 ? y >> 1 : y) * pitch_c + c];
+      if (vsub == 1) {                                   // h2v1
+        const int v0 = p[(size_t)y * pitch_c + c];
+        if (x == 0 || x == 2 * cw - 1) return v0;
+        return (x & 1) ? (3 * v0 + p[(size_t)y * pitch_c + c + 1] + 2) >> 2 : (3 * v0 + p[(size_t)y * pitch_c + c - 1] + 1) >> 2;
+      }
+      const int rr = y >> 1, far = (y & 1) ? min(rr + 1, ch - 1) : max(rr - 1, 0);
+      auto colsum = [&](int cc) { return 3 * (int)p[(size_t)rr * pitch_c + cc] + (int)p[(size_t)far * pitch_c + cc]; };
+      const int s0 = colsum(c);
+      if (x == 0) return (s0 * 4 + 8) >> 4;
+      if (x == 2 * cw - 1) return (s0 * 4 + 7) >> 4;
+      return (x & 1) ? (3 * s0 + colsum(c + 1) + 7) >> 4 : (3 * s0 + colsum(c - 1) + 8) >> 4;
+    };
+    cbv = up(pcb) - 128;
+    crv = up(pcr) - 128;
+    r = Y + ((91881 * crv + 32768) >> 16);
+    g = Y + ((-22554 * cbv + 32768 - 46802 * crv) >> 16);
+    b = Y + ((116130 * cbv + 32768) >> 16);
+    r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
+  }
+  unsigned char* o = out + (size_t)y * stride + (size_t)x * 3;
+  o[0] = (unsigned char)(bgr ? b : r); o[1] = (unsigned char)g; o[2] = (unsigned char)(bgr ? r : b);
+}
+
+}  // namespace
+
+void jpeg_reconstruct_device(const JpegScan& s, unsigned char* d_out, long long stride, int bgr, hipStream_t st) {
+  DevBuf coef[3], plane[3], qt(sizeof(unsigned short) * 64 * 4);
+  FFP_HIP(hipMemcpyAsync(qt.p, s.qt, sizeof(unsigned short) * 64 * 4, hipMemcpyHostToDevice, st));
+  for (int c = 0; c < s.ncomp; ++c) {
+    const JpegComp& cp = s.comp[c];
+    const int nb = cp.blocks_x * cp.blocks_y;
+    coef[c] = DevBuf((size_t)nb * 64 * sizeof(short));
+    plane[c] = DevBuf((size_t)nb * 64 + 16);
+    FFP_HIP(hipMemcpyAsync(coef[c].p, s.coef[c].data(), (size_t)nb * 64 * sizeof(short), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nb + 7) / 8), dim3(64), 0, st, coef[c].as<short>(), nb, cp.blocks_x, qt.as<unsigned short>() + 64 * cp.tq,
+                       plane[c].as<unsigned char>());
+  }
+  const int hsub = s.ncomp == 3 ? s.hmax : 1, vsub = s.ncomp == 3 ? s.vmax : 1;
+  const int ch = (s.h + vsub - 1) / vsub, cw = (s.w + hsub - 1) / hsub;
+  hipLaunchKernelGGL(jpeg_colour_kernel, dim3((s.w + 255) / 256, s.h), dim3(256), 0, st, plane[0].as<unsigned char>(),
+                     s.ncomp == 3 ? plane[1].as<unsigned char>() : nullptr, s.ncomp == 3 ? plane[2].as<unsigned char>() : nullptr, s.h, s.w,
+                     s.comp[0].blocks_x * 8, s.ncomp == 3 ? s.comp[1].blocks_x * 8 : 0, ch, cw, hsub, vsub, s.ncomp, bgr, stride, d_out);
+  FFP_HIP(hipGetLastError());
+  FFP_HIP(hipStreamSynchronize(st));                   // the staging buffers die with this frame
 }
 
 }  // namespace ffp

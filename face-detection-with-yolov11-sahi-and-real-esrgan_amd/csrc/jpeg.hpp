@@ -9,8 +9,27 @@ namespace ffp {
 // SOI .. SOS of the file libjpeg writes for an h x w three-component 4:2:0 baseline image at `quality`
 std::vector<unsigned char> jpeg_header(int h, int w, int quality);
 
+// One launch sequence for a whole batch of device-resident images (e.g. the enhanced crops of a frame in the SR output buffer):
+// files[i] = the JFIF file of src[i]. Two stream synchronisations per batch, whatever its size.
+struct JpegSrc { const unsigned char* d_img; int h, w; long long stride; };
+void jpeg_encode_batch_device(const JpegSrc* src, int n_img, int bgr, int quality, std::vector<std::vector<unsigned char>>& files, hipStream_t st);
+
 // Encodes the h x w x 3 uint8 image at d_img (row pitch `stride` bytes, channel order RGB or BGR) into `out` (host, `cap` bytes):
 // the whole JFIF file. Returns its size, or minus the size needed when out is null or too small. Synchronises `st`.
 long long jpeg_encode_device(const unsigned char* d_img, int h, int w, long long stride, int bgr, int quality, unsigned char* out, long long cap, hipStream_t st);
+
+// ---- decoding: host entropy decoding (jpeg_dec.cpp) + device reconstruction (jpeg.hip) ------------------------------------------------
+struct JpegComp { int hs = 1, vs = 1, tq = 0, td = 0, ta = 0, blocks_x = 0, blocks_y = 0; };
+struct JpegScan {
+  int h = 0, w = 0, ncomp = 0, hmax = 1, vmax = 1;
+  JpegComp comp[3];
+  unsigned short qt[4][64];                     // natural order
+  std::vector<short> coef[3];                   // [blocks_y][blocks_x][64] natural order, quantised
+};
+// markers + Huffman decoding of a baseline / extended-sequential 8-bit JFIF file (one interleaved scan, 1 or 3 components, chroma
+// at full, half-width or half-width-half-height resolution; restart intervals). Throws ffp::Error on anything else.
+void jpeg_entropy_decode(const unsigned char* data, long long n, JpegScan& out, bool header_only);
+// dequantisation + integer IDCT + upsampling + colour conversion into d_out (h x w x 3 uint8, row pitch `stride`, RGB or BGR)
+void jpeg_reconstruct_device(const JpegScan& s, unsigned char* d_out, long long stride, int bgr, hipStream_t st);
 
 }  // namespace ffp

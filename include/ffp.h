@@ -250,6 +250,23 @@ int ffp_eval_dual_match(int device, const double* preds, const int64_t* pred_off
 int ffp_jpeg_encode(int device, const uint8_t* img, int h, int w, int bgr, int quality, uint8_t* out, int64_t cap, int64_t* out_size);
 int ffp_jpeg_encode_dev(int device, const uint8_t* d_img, int h, int w, int64_t row_stride, int bgr, int quality, uint8_t* out, int64_t cap,
                         int64_t* out_size);
+/* The per-crop loop of enhance_face_crops_batch (/root/reference/utils/enhancer.py:344-391: one cv2.imwrite per enhanced crop) as ONE
+ * pass over n device-resident images: image i is hs[i] x ws[i] x 3 at d_base + offsets[i] (row pitch strides[i], or ws[i]*3 when
+ * strides is NULL) — e.g. the out_offsets layout of ffp_sr_enhance_crops_dev with hs/ws = 4 x the crop sizes. File i is
+ * out[out_offsets[i] .. out_offsets[i+1]) (out_offsets has n+1 entries and is filled even when cap is too small: FFP_ERR_ARG). */
+int ffp_jpeg_encode_batch_dev(int device, const uint8_t* d_base, int n, const int64_t* offsets, const int32_t* hs, const int32_t* ws, const int64_t* strides,
+                              int bgr, int quality, uint8_t* out, int64_t cap, int64_t* out_offsets);
+
+/* Replaces `cv2.imread(path)` for .jpg files (/root/reference/utils/enhancer.py:254, utils/visualization.py:200, and the image
+ * load inside sahi's get_sliced_prediction): baseline / extended-sequential 8-bit JFIF, 4:4:4 / 4:2:2 / 4:2:0 or grayscale, restart
+ * intervals; libjpeg's default reconstruction (integer IDCT, triangle chroma upsampling, fixed-point YCbCr -> RGB), pixel-identical
+ * to what libjpeg-turbo returns. The Huffman decoder runs on the host (a serial bit stream); IDCT, upsampling and colour conversion
+ * run on the device. Progressive / arithmetic-coded files: FFP_ERR_ARG. ffp_jpeg_info reads the header only. out: h*w*3 bytes, BGR
+ * when bgr = 1 (cv2's order; grayscale files give three equal channels like IMREAD_COLOR). _dev writes into device memory (row
+ * pitch in bytes): the frame is ready for ffp_sliced_predict_dev without an upload of the pixels. */
+int ffp_jpeg_info(const uint8_t* data, int64_t n, int32_t* out_h, int32_t* out_w, int32_t* out_ncomp);
+int ffp_jpeg_decode(int device, const uint8_t* data, int64_t n, int bgr, uint8_t* out, int64_t cap);
+int ffp_jpeg_decode_dev(int device, const uint8_t* data, int64_t n, int bgr, uint8_t* d_out, int64_t row_stride, int64_t cap);
 
 /* 1x1 conv over the virtual concat [nearest_x2(coarse) | fine] (the YOLO neck's Upsample + Concat + C3k2.cv1 without
  * materialising the upsampled tensor: /root/reference's model graph via ultralytics' yolo11-pose.yaml layers 11-13 and 14-16).

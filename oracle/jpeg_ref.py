@@ -250,3 +250,219 @@ def encode(rgb: np.ndarray, quality: int = 95) -> bytes:
             last[2] = encode_block(bw, crq[my, mx].reshape(64)[ZIGZAG], last[2], dcc, acc)
     bw.flush()
     return header(rgb.shape[0], rgb.shape[1], quality) + bytes(bw.out) + bytes([0xFF, 0xD9])
+
+
+# ---- decoding (cv2.imread's default path: islow IDCT, fancy upsampling, YCbCr -> RGB) -------------------------------------------------
+def parse(data: bytes) -> dict:
+    """Markers of a baseline / extended-sequential 8-bit JFIF file with one interleaved scan (what cv2.imwrite and cameras write;
+    progressive files are a different entropy coder and are rejected)."""
+    assert data[:2] == b"\xff\xd8", "not a JPEG"
+    i, out = 2, {"qt": {}, "ht": {}, "dri": 0}
+    while True:
+        assert data[i] == 0xFF, "marker expected"
+        while data[i + 1] == 0xFF:
+            i += 1
+        m = data[i + 1]
+        L = (data[i + 2] << 8) | data[i + 3]
+        seg = data[i + 4:i + 2 + L]
+        if m == 0xDB:
+            k = 0
+            while k < len(seg):
+                pq, tq = seg[k] >> 4, seg[k] & 15
+                assert pq == 0, "16-bit quantisation tables"
+                t = np.zeros(64, np.int32)
+                t[ZIGZAG] = np.frombuffer(seg[k + 1:k + 65], np.uint8)
+                out["qt"][tq] = t
+                k += 65
+        elif m == 0xC4:
+            k = 0
+            while k < len(seg):
+                bits = list(seg[k + 1:k + 17])
+                n = sum(bits)
+                out["ht"][seg[k]] = (bits, list(seg[k + 17:k + 17 + n]))
+                k += 17 + n
+        elif m in (0xC0, 0xC1):
+            assert seg[0] == 8
+            out["h"], out["w"] = (seg[1] << 8) | seg[2], (seg[3] << 8) | seg[4]
+            out["comps"] = [{"id": seg[6 + 3 * c], "hs": seg[7 + 3 * c] >> 4, "vs": seg[7 + 3 * c] & 15, "tq": seg[8 + 3 * c]} for c in range(seg[5])]
+        elif m in (0xC2, 0xC3, 0xC5, 0xC6, 0xC7, 0xC9, 0xCA, 0xCB, 0xCD, 0xCE, 0xCF):
+            raise ValueError("unsupported JPEG process (progressive / lossless / arithmetic)")
+        elif m == 0xDD:
+            out["dri"] = (seg[0] << 8) | seg[1]
+        elif m == 0xDA:
+            ns = seg[0]
+            assert ns == len(out["comps"]), "non-interleaved scans"
+            for c in range(ns):
+                comp = next(x for x in out["comps"] if x["id"] == seg[1 + 2 * c])
+                comp["td"], comp["ta"] = seg[2 + 2 * c] >> 4, seg[2 + 2 * c] & 15
+            out["scan"] = i + 2 + L
+            return out
+        i += 2 + L
+
+
+def decode_coefficients(data: bytes, info: dict):
+    """jdhuff.c decode_mcu over the whole scan -> per component [blocks_y][blocks_x][64] coefficients in natural order (not yet
+    dequantised), block grids padded to whole MCUs."""
+    hmax, vmax = max(c["hs"] for c in info["comps"]), max(c["vs"] for c in info["comps"])
+    mx, my = -(-info["w"] // (8 * hmax)), -(-info["h"] // (8 * vmax))
+    look = {}
+    for key, (bits, vals) in info["ht"].items():
+        d, code, k = {}, 0, 0
+        for l in range(1, 17):
+            for _ in range(bits[l - 1]):
+                d[(l, code)] = vals[k]
+                code += 1
+                k += 1
+            code <<= 1
+        look[key] = d
+    coefs = [np.zeros((my * c["vs"], mx * c["hs"], 64), np.int32) for c in info["comps"]]
+    pos, acc, nb = info["scan"], 0, 0
+
+    def bit():
+        nonlocal pos, acc, nb
+        if nb == 0:
+            b = data[pos]
+            pos += 1
+            if b == 0xFF:
+                assert data[pos] == 0, "marker inside entropy-coded data"
+                pos += 1
+            acc, nb = b, 8
+        nb -= 1
+        return (acc >> nb) & 1
+
+    def sym(tab):
+        code, l = 0, 0
+        while True:
+            code = (code << 1) | bit()
+            l += 1
+            if (l, code) in tab:
+                return tab[(l, code)]
+            assert l < 16, "bad Huffman code"
+
+    def receive(n):
+        v = 0
+        for _ in range(n):
+            v = (v << 1) | bit()
+        return v if n == 0 or v >= (1 << (n - 1)) else v - (1 << n) + 1
+
+    last = [0] * len(info["comps"])
+    count = 0
+    for m_y in range(my):
+        for m_x in range(mx):
+            if info["dri"] and count and count % info["dri"] == 0:
+                nb = 0                                              # byte-align, skip RSTn, reset predictions
+                assert data[pos] == 0xFF and 0xD0 <= data[pos + 1] <= 0xD7
+                pos += 2
+                last = [0] * len(info["comps"])
+            count += 1
+            for ci, c in enumerate(info["comps"]):
+                for dy in range(c["vs"]):
+                    for dx in range(c["hs"]):
+                        blk = coefs[ci][m_y * c["vs"] + dy, m_x * c["hs"] + dx]
+                        s = sym(look[c["td"]])
+                        last[ci] += receive(s)
+                        blk[0] = last[ci]
+                        k = 1
+                        while k < 64:
+                            rs = sym(look[0x10 | c["ta"]])
+                            r, s = rs >> 4, rs & 15
+                            if s == 0:
+                                if r != 15:
+                                    break
+                                k += 16
+                                continue
+                            k += r
+                            blk[ZIGZAG[k]] = receive(s)
+                            k += 1
+    return coefs
+
+
+def _idct_1d(v, first):
+    """jidctint.c one 8-point pass on [..., 8] (already dequantised); first: columns (keeps 2 extra bits), second: rows (+ range shift)."""
+    v = [v[..., i].astype(np.int64) for i in range(8)]
+    z2, z3 = v[2], v[6]
+    z1 = (z2 + z3) * C["f0_541"]
+    t2, t3 = z1 - z3 * C["f1_847"], z1 + z2 * C["f0_765"]
+    t0, t1 = (v[0] + v[4]) << 13, (v[0] - v[4]) << 13
+    t10, t13, t11, t12 = t0 + t3, t0 - t3, t1 + t2, t1 - t2
+    t0, t1, t2, t3 = v[7], v[5], v[3], v[1]
+    z1, z2, z3, z4 = t0 + t3, t1 + t2, t0 + t2, t1 + t3
+    z5 = (z3 + z4) * C["f1_175"]
+    t0, t1, t2, t3 = t0 * C["f0_298"], t1 * C["f2_053"], t2 * C["f3_072"], t3 * C["f1_501"]
+    z1, z2, z3, z4 = -z1 * C["f0_899"], -z2 * C["f2_562"], -z3 * C["f1_961"] + z5, -z4 * C["f0_390"] + z5
+    t0, t1, t2, t3 = t0 + z1 + z3, t1 + z2 + z4, t2 + z2 + z3, t3 + z1 + z4
+    n = 11 if first else 18
+    return np.stack([_descale(t10 + t3, n), _descale(t11 + t2, n), _descale(t12 + t1, n), _descale(t13 + t0, n),
+                     _descale(t13 - t0, n), _descale(t12 - t1, n), _descale(t11 - t2, n), _descale(t10 - t3, n)], -1)
+
+
+def idct_islow(coef: np.ndarray, qt: np.ndarray) -> np.ndarray:
+    """[by][bx][64] quantised coefficients -> sample plane (uint8 range), jidctint.c jpeg_idct_islow."""
+    d = (coef * qt[None, None, :]).reshape(coef.shape[0], coef.shape[1], 8, 8)
+    cols = np.swapaxes(_idct_1d(np.swapaxes(d, -1, -2), True), -1, -2)
+    rows = _idct_1d(cols, False)
+    out = np.clip(rows + 128, 0, 255)
+    return out.swapaxes(1, 2).reshape(coef.shape[0] * 8, coef.shape[1] * 8).astype(np.int32)
+
+
+def h2v1_fancy(p: np.ndarray) -> np.ndarray:
+    """jdsample.c h2v1_fancy_upsample: 3/4 nearer + 1/4 further sample, rounding 1 / 2 alternately, edge columns copied."""
+    w = p.shape[1]
+    out = np.zeros((p.shape[0], 2 * w), np.int32)
+    left, right = np.concatenate([p[:, :1], p[:, :-1]], 1), np.concatenate([p[:, 1:], p[:, -1:]], 1)
+    out[:, 0::2] = (3 * p + left + 1) >> 2
+    out[:, 1::2] = (3 * p + right + 2) >> 2
+    out[:, 0], out[:, -1] = p[:, 0], p[:, -1]
+    return out
+
+
+def h2v2_fancy(p: np.ndarray) -> np.ndarray:
+    """jdsample.c h2v2_fancy_upsample: triangle filter in both directions (9/16, 3/16, 3/16, 1/16), vertical neighbours from the row
+    above / below with the image's first / last row replicated (jdmainct.c context rows)."""
+    up, dn = np.concatenate([p[:1], p[:-1]], 0), np.concatenate([p[1:], p[-1:]], 0)
+    out = np.zeros((2 * p.shape[0], 2 * p.shape[1]), np.int32)
+    for v, near_far in enumerate((3 * p + up, 3 * p + dn)):
+        s = near_far.astype(np.int64)
+        left, right = np.concatenate([s[:, :1], s[:, :-1]], 1), np.concatenate([s[:, 1:], s[:, -1:]], 1)
+        row = np.zeros((s.shape[0], 2 * s.shape[1]), np.int64)
+        row[:, 0::2] = (3 * s + left + 8) >> 4
+        row[:, 1::2] = (3 * s + right + 7) >> 4
+        row[:, 0], row[:, -1] = (s[:, 0] * 4 + 8) >> 4, (s[:, -1] * 4 + 7) >> 4
+        out[v::2] = row
+    return out
+
+
+def ycc_to_rgb(y, cb, cr) -> np.ndarray:
+    """jdcolor.c ycc_rgb_convert (16-bit fixed-point tables)."""
+    y, cb, cr = y.astype(np.int64), cb.astype(np.int64) - 128, cr.astype(np.int64) - 128
+    r = y + ((fix(1.40200) * cr + 32768) >> 16)
+    g = y + ((-fix(0.34414) * cb + 32768 - fix(0.71414) * cr) >> 16)
+    b = y + ((fix(1.77200) * cb + 32768) >> 16)
+    return np.clip(np.stack([r, g, b], -1), 0, 255).astype(np.uint8)
+
+
+def decode(data: bytes) -> np.ndarray:
+    """JFIF file -> H x W x 3 uint8 RGB as libjpeg(-turbo) decodes it by default (grayscale files come back with three equal channels,
+    like cv2.imread's default flag)."""
+    info = parse(data)
+    coefs = decode_coefficients(data, info)
+    h, w = info["h"], info["w"]
+    hmax, vmax = max(c["hs"] for c in info["comps"]), max(c["vs"] for c in info["comps"])
+    planes = []
+    for c, co in zip(info["comps"], coefs):
+        p = idct_islow(co, info["qt"][c["tq"]])
+        ch, cw = -(-h * c["vs"] // vmax), -(-w * c["hs"] // hmax)          # the component's own size (jdmaster.c downsampled_height / width)
+        p = p[:ch, :cw]
+        fancy = cw > 2                                   # jdsample.c jinit_upsampler: narrower components are replicated, not filtered
+        if c["hs"] == hmax and c["vs"] == vmax:
+            pass
+        elif c["hs"] * 2 == hmax and c["vs"] * 2 == vmax:
+            p = h2v2_fancy(p) if fancy else np.repeat(np.repeat(p, 2, 0), 2, 1)
+        elif c["hs"] * 2 == hmax and c["vs"] == vmax:
+            p = h2v1_fancy(p) if fancy else np.repeat(p, 2, 1)
+        else:
+            raise ValueError("unsupported sampling factors")
+        planes.append(p[:h, :w])
+    if len(planes) == 1:
+        return np.repeat(planes[0][..., None], 3, -1).astype(np.uint8)
+    return ycc_to_rgb(*planes)
