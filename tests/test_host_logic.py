@@ -127,6 +127,8 @@ def test_pmc_symbol_to_variant_mapping():
     assert v("_ZN3ffp16conv_mfma_kernelIDF16_Li3ELi1ELi4ELi1ELi2ELi1ELi16EEEvNS_8ConvArgsE") == "f16_k3s1_narrow1"
     assert v("void ffp::conv_mfma_kernel<float, 1, 1, 2, 2, 2, 2, 32>(ffp::ConvArgs)") == "f32_k1s1_wideH"
     assert v("ffp::(anonymous namespace)::conv_rows16_kernel(ffp::ConvArgs)") == "f16_k3s1_rows16"
+    assert v("void ffp::(anonymous namespace)::conv_pw_kernel<8, 1, 4, 3, false>(ffp::ConvArgs)") == "f32x3_k1s1_pw1x4w"
+    assert v("_ZN3ffp12_GLOBAL__N_114conv_pw_kernelILi4ELi2ELi2ELi2ELb1EEEvNS_8ConvArgsE") == "f32x3_k1s1_pw2x2"
     assert v("__amd_rocclr_copyBuffer") is None
 
 
