@@ -273,6 +273,8 @@ class Runner:
 
     def loop(self, n_steps, profile_last=False):
         gs = self.groups(n_steps)
+        if not gs:                                     # --warmup 0
+            return
         # SR kernels are profiled on the last FULL batch of the loop (a trailing partial batch would understate the launch sizes)
         n_flush = -(-(n_steps * self.B) // self.SB) if self.args.sr_crops > 0 else 0
         n_full = (n_steps * self.B) // self.SB
