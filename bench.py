@@ -34,8 +34,8 @@ PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32x3": 2500.0 / 3}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--slice", type=int, default=512)
@@ -57,9 +57,9 @@ def parse():
     ap.add_argument("--exchange", default="auto", choices=["auto", "always", "never"],
                     help="all-gather of the per-item detections: auto = only when a frame's items are spread over ranks")
     ap.add_argument("--resident", action="store_true", help="frames already in HBM when the timed region starts (no upload in the span)")
-    ap.add_argument("--sr-batch-frames", type=int, default=8,
+    ap.add_argument("--sr-batch-frames", type=int, default=10,
                     help="frames whose crops are enhanced together as one ragged Real-ESRGAN batch (1: per frame)")
-    ap.add_argument("--det-batch-frames", type=int, default=4,
+    ap.add_argument("--det-batch-frames", type=int, default=5,
                     help="consecutive steps whose frames are detected together as one ragged batch of slices (1: per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", action="store_true", help="CPU baseline on a bounded sample (3 slices + 3 crops) instead of one whole frame")
