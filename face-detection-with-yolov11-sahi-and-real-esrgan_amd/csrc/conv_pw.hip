@@ -30,8 +30,12 @@ constexpr unsigned PW_OOB = 0x80000000u;      // beyond any num_records we set (
 // of it for the 8-wave shapes (one workgroup per CU, twice the input channels for the same register budget per wave)
 constexpr int pw_lds_frags(int nw) { return nw == 8 ? 80 : 40; }
 
-template <int NW, int MI, int NT, int RP, bool UP>
-__global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvArgs a) {
+// ST (deep inputs whose weights do not fit the LDS): one EXTRA wave per workgroup streams the weights — RP line-groups per stage, two
+// stages — while the NW consumer waves multiply out of the other stage; one barrier per RP line-groups. The producer has its own
+// in-order load counter: a consumer that waited for weights it had loaded itself would also wait for every activation load issued
+// before them (measured: that variant lost 1.5x), and the consumers' activation ring stays as deep as in the resident form.
+template <int NW, int MI, int NT, int RP, bool UP, bool ST = false>
+__global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BPX = NW * 32 * MI;            // pixels per work item: NW waves x MI fragments of 32
   const int tid = threadIdx.x, lane = tid & 63;
@@ -67,8 +71,43 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvArgs a) {
   };
 
   // ---- weights of this channel block -> LDS, [nt][k-group] x {hi 1 KiB, lo 1 KiB}: one contiguous run of the packed array
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)ntile0 * ncg * 2048);
+  constexpr int CKG = 2 * RP;                  // ST: k-groups per stage; a stage is [nt][CKG] x 2 KiB
+  constexpr int STAGE = NT * CKG * 2048;
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)ntile0 * ncg * 2048;
+  if constexpr (ST) {
+    if (wave == NW) {
+      // ---- the producer wave: chunk 0 before the first barrier, then chunk i + 1 into the idle stage during chunk i, in 1 KiB pieces
+      // (64 lanes x 16 B) with 8 loads in flight; it takes part in every barrier of the consumers' schedule and does nothing else
+      const int nchunks = npairs / RP;
+      constexpr int PIECES = NT * CKG * 2;
+      auto copy_chunk = [&](int c, unsigned char* stage) {
+        uint4 buf[8];
+#pragma unroll 1
+        for (int p0 = 0; p0 < PIECES; p0 += 8) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int pc = p0 + i, nt = pc / (2 * CKG), off = (pc % (2 * CKG)) * 1024;
+            if (pc < PIECES) buf[i] = *reinterpret_cast<const uint4*>(wsrc + ((size_t)nt * ncg + (size_t)c * CKG) * 2048 + off + lane * 16);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int pc = p0 + i, nt = pc / (2 * CKG), off = (pc % (2 * CKG)) * 1024;
+            if (pc < PIECES) *reinterpret_cast<uint4*>(stage + nt * (CKG * 2048) + off + lane * 16) = buf[i];
+          }
+        }
+      };
+      copy_chunk(0, smem);
+      __syncthreads();
+      int it = 0;
+      for (int pbp = slot; pbp < PB; pbp += nslots)
+        for (int c = 0; c < nchunks; ++c, ++it) {
+          copy_chunk(c + 1 < nchunks ? c + 1 : 0, smem + ((it + 1) & 1) * STAGE);
+          __syncthreads();
+        }
+      return;
+    }
+  } else {
+    const uint4* src = reinterpret_cast<const uint4*>(wsrc);
     const int nv = NT * ncg * 128;
     for (int i = tid; i < nv; i += NW * 64) reinterpret_cast<uint4*>(smem)[i] = src[i];
   }
@@ -164,6 +203,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvArgs a) {
   uint4 wq[2][2];                              // weight fragment ring {hi, lo} x 2 steps
   wq[0][0] = *reinterpret_cast<const uint4*>(wl0);
   wq[0][1] = *reinterpret_cast<const uint4*>(wl0 + 1024);
+  int it = 0;                                  // ST: chunks done so far; the current stage is it & 1
   for (; pb < PB; pb += nslots) {
     const Span rs_next = block_span(a.in, pb + nslots, a.in_cs, a.in_coff);
     if constexpr (UP) load_vup(pb + nslots, vup_next);
@@ -186,9 +226,10 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvArgs a) {
         // 2 * NT steps (k-group q = j / NT, channel tile nt = j % NT) of 3 * MI MFMAs; the weight fragments of step j + 1 are
         // requested from LDS before the MFMAs of step j issue (two-deep register ring carried over slots, blocks and items)
         const int pr_nx = r + 1 < RP ? kb + r + 1 : prb;              // line-group whose first fragments the last step requests
-        const unsigned char* wp = wl0 + 2 * (kb + r) * 2048;
-        const unsigned char* wp_nx = wl0 + 2 * pr_nx * 2048;
-        const int wstride = ncg * 2048;
+        const unsigned char* wbase = ST ? wl0 + (it & 1) * STAGE : wl0;
+        const unsigned char* wp = wbase + 2 * (ST ? r : kb + r) * 2048;
+        const unsigned char* wp_nx = ST ? wp + 4096 : wl0 + 2 * pr_nx * 2048;      // ST: never read for the last line-group of a stage
+        const int wstride = ST ? CKG * 2048 : ncg * 2048;
         f16x8 ph[MI], pl[MI];
 #pragma unroll
         for (int j = 0; j < 2 * NT; ++j) {
@@ -210,8 +251,10 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvArgs a) {
             }
           }
           const unsigned char* nx = j + 1 < 2 * NT ? wp + ((j + 1) / NT) * 2048 + ((j + 1) % NT) * wstride : wp_nx;
-          wq[(j + 1) & 1][0] = *reinterpret_cast<const uint4*>(nx);
-          wq[(j + 1) & 1][1] = *reinterpret_cast<const uint4*>(nx + 1024);
+          if (!(ST && r == RP - 1 && j + 1 == 2 * NT)) {             // (the next stage is complete only after the barrier below)
+            wq[(j + 1) & 1][0] = *reinterpret_cast<const uint4*>(nx);
+            wq[(j + 1) & 1][1] = *reinterpret_cast<const uint4*>(nx + 1024);
+          }
           union { uint4 u; f16x8 h; } wh, wl;
           wh.u = wq[j & 1][0];
           wl.u = wq[j & 1][1];
@@ -224,6 +267,12 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvArgs a) {
           __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);         // the two reads for step j + 1, then this step's MFMAs
           __builtin_amdgcn_sched_group_barrier(0x008, 3 * MI, 0);
         }
+      }
+      if constexpr (ST) {                                            // the producer has filled the other stage; everyone is done with this one
+        __syncthreads();
+        ++it;
+        wq[0][0] = *reinterpret_cast<const uint4*>(wl0 + (it & 1) * STAGE);
+        wq[0][1] = *reinterpret_cast<const uint4*>(wl0 + (it & 1) * STAGE + 1024);
       }
     }
 
@@ -290,6 +339,25 @@ template <int NW, int MI, int NT, int RPMAX> struct PwShape {
   }
 };
 
+// 16: 7 consumer waves + the weight producer, 128 channels per workgroup, any K that is a multiple of 128
+struct Pw14s {
+  static constexpr int NWC = 7, RP = 4, NT = 4, LDS = 2 * NT * 2 * RP * 2048;
+  static bool fits(const ConvArgs& a) { return a.ntiles32 % NT == 0 && (a.ncg / 2) % RP == 0; }
+  static void init() {
+    FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<NWC, 1, NT, RP, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<NWC, 1, NT, RP, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+  }
+  static void launch(ConvArgs& a, hipStream_t st) {
+    constexpr int BPX = NWC * 32;
+    const int pbn = (int)((a.total_px + BPX - 1) / BPX);
+    a.n_nblk = a.ntiles32 / NT;
+    const int nslots = std::min(pbn, std::max(1, 256 / a.n_nblk));
+    if (nslots == 0) return;
+    if (a.up_c > 0) hipLaunchKernelGGL((conv_pw_kernel<NWC, 1, NT, RP, true, true>), dim3(nslots * a.n_nblk), dim3((NWC + 1) * 64), LDS, st, a);
+    else hipLaunchKernelGGL((conv_pw_kernel<NWC, 1, NT, RP, false, true>), dim3(nslots * a.n_nblk), dim3((NWC + 1) * 64), LDS, st, a);
+  }
+};
+
 using Pw14 = PwShape<4, 1, 4, 4>;      // force_shape 10: 128 px x 128 ch per workgroup, K <= 160
 using Pw22 = PwShape<4, 2, 2, 2>;      // 11: 256 px x 64 ch, K <= 320
 using Pw21 = PwShape<4, 2, 1, 4>;      // 12: 256 px x 32 ch, K <= 640
@@ -299,7 +367,7 @@ using Pw21w = PwShape<8, 2, 1, 4>;
 
 }  // namespace
 
-void conv_pw_init() { Pw14::init(); Pw22::init(); Pw21::init(); Pw14w::init(); Pw22w::init(); Pw21w::init(); }
+void conv_pw_init() { Pw14::init(); Pw22::init(); Pw21::init(); Pw14w::init(); Pw22w::init(); Pw21w::init(); Pw14s::init(); }
 
 // what the kernel does not do: residual inputs, fp16 outputs, input channel counts that are not whole 128-byte lines
 static bool pw_common(const ConvOp& op, const ConvArgs& a) {
@@ -318,6 +386,7 @@ unsigned conv_pw_mask(const ConvOp& op, const ConvArgs& a) {
   if (Pw14w::fits(a)) m |= 1u << 13;
   if (Pw22w::fits(a)) m |= 1u << 14;
   if (Pw21w::fits(a)) m |= 1u << 15;
+  if (Pw14s::fits(a)) m |= 1u << 16;
   return m;
 }
 
@@ -328,7 +397,8 @@ void launch_conv_pw(ConvArgs& a, int shape, hipStream_t st) {
     case 12: Pw21::launch(a, st); break;
     case 13: Pw14w::launch(a, st); break;
     case 14: Pw22w::launch(a, st); break;
-    default: Pw21w::launch(a, st); break;
+    case 15: Pw21w::launch(a, st); break;
+    default: Pw14s::launch(a, st); break;
   }
 }
 

@@ -276,7 +276,7 @@ int ffp_op_conv1x1_up2(int device, int precision, const float* coarse, const flo
                        const float* wt, const float* bias, int cout, int act, float* y);
 
 /* Tuning / test hook: pin the workgroup shape ffp_op_conv2d uses from now on (process-wide; -1 = automatic, the default).
- * 0..5 generic shapes, 9 conv_rows16, 10..12 the pointwise kernels of conv_pw.hip. A shape that cannot run the op is an error
+ * 0..5 generic shapes, 9 conv_rows16, 10..16 the pointwise kernels of conv_pw.hip. A shape that cannot run the op is an error
  * of the following ffp_op_conv2d call. */
 int ffp_op_conv2d_shape(int force_shape);
 

@@ -190,12 +190,15 @@ def test_f32x3_scaled_split_is_fp32_grade_over_ranges(gpu_lib, name, shape):
     assert errs["f32x3"] <= 1e-5, (name, errs)
 
 
-PW_SHAPES = {10: (4, 40), 11: (2, 40), 12: (1, 40), 13: (4, 80), 14: (2, 80), 15: (1, 80)}      # force_shape -> (32-channel tiles per workgroup, LDS fragments)
+# force_shape -> (32-channel tiles per workgroup, LDS-resident weight fragments; 0: weights streamed by a producer wave, cin a multiple of 128)
+PW_SHAPES = {10: (4, 40), 11: (2, 40), 12: (1, 40), 13: (4, 80), 14: (2, 80), 15: (1, 80), 16: (4, 0)}
 
 
 def pw_can_run(shape, cin, cout):
     nt, frags = PW_SHAPES[shape]
-    return cin % 32 == 0 and (-(-cout // 32)) % nt == 0 and nt * (cin // 16) <= frags
+    if (-(-cout // 32)) % nt:
+        return False
+    return cin % 128 == 0 if frags == 0 else (cin % 32 == 0 and nt * (cin // 16) <= frags)
 
 
 PW_CASES = [
@@ -210,8 +213,10 @@ PW_CASES = [
     (1, 16, 16, 256, 256, 0),
     (5, 128, 128, 96, 128, 1),      # 81920 pixels: every workgroup walks several pixel blocks with resident weights
     (9, 96, 96, 64, 64, 1),
-    (2, 32, 32, 1024, 512, 1),      # K = 1024: one 32-channel tile per 8-wave workgroup is all that stays resident
+    (2, 32, 32, 1024, 512, 1),      # K = 1024: one 32-channel tile per 8-wave workgroup is all that stays resident; streamed weights take 128
     (9, 64, 64, 384, 128, 1),
+    (11, 64, 64, 768, 256, 1),      # streamed weights, several pixel blocks per workgroup (stage parity carries over blocks)
+    (1, 15, 15, 128, 128, 0),       # one stage per block
 ]
 
 
