@@ -129,6 +129,9 @@ def test_pmc_symbol_to_variant_mapping():
     assert v("ffp::(anonymous namespace)::conv_rows16_kernel(ffp::ConvArgs)") == "f16_k3s1_rows16"
     assert v("void ffp::(anonymous namespace)::conv_pw_kernel<8, 1, 4, 3, false>(ffp::ConvArgs)") == "f32x3_k1s1_pw1x4w"
     assert v("_ZN3ffp12_GLOBAL__N_114conv_pw_kernelILi4ELi2ELi2ELi2ELb1EEEvNS_8ConvArgsE") == "f32x3_k1s1_pw2x2"
+    assert v("void ffp::(anonymous namespace)::conv_pw_kernel<8, 2, 2, 2, true, false>(ffp::ConvArgs)") == "f32x3_k1s1_pw2x2w"
+    assert v("void ffp::(anonymous namespace)::conv_pw_kernel<7, 1, 4, 4, false, true>(ffp::ConvArgs)") == "f32x3_k1s1_pw1x4s"
+    assert v("_ZN3ffp12_GLOBAL__N_114conv_pw_kernelILi7ELi1ELi4ELi4ELb1ELb1EEEvNS_8ConvArgsE") == "f32x3_k1s1_pw1x4s"
     assert v("__amd_rocclr_copyBuffer") is None
 
 

@@ -15,10 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def variant(sym: str):
     if "conv_rows16_kernel" in sym:
         return "f16_k3s1_rows16"
-    m = re.search(r"conv_pw_kernel<(\d+), *(\d+), *(\d+), *(\d+), *(true|false)>", sym) or re.search(r"conv_pw_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])E", sym)
+    m = re.search(r"conv_pw_kernel<(\d+), *(\d+), *(\d+), *(\d+), *(true|false)(?:, *(true|false))?>", sym) or \
+        re.search(r"conv_pw_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])E(?:Lb([01])E)?", sym)
     if m:                                                   # waves, pixel fragments, channel tiles (ring depth and the x2-source flag do not name a variant)
         nw, mi, nt = int(m.group(1)), int(m.group(2)), int(m.group(3))
-        return f"f32x3_k1s1_pw{mi}x{nt}" + ("w" if nw == 8 else "")
+        stream = m.group(6) in ("true", "1")
+        return f"f32x3_k1s1_pw{mi}x{nt}" + ("s" if stream else "w" if nw == 8 else "")
     m = re.search(r"conv_rows_kernel<(\d+), *(\d+)>", sym) or re.search(r"conv_rows_kernelILi(\d+)ELi(\d+)E", sym)
     if m:
         return "f16_k3s1_rows"
