@@ -398,7 +398,7 @@ def main():
                 r = sec("one_frame_across_ranks", frames_per_step=1, exchange="auto", det_batch=1)      # ONE frame's 61 items over the ranks
                 secondary["one_frame_across_ranks"]["scaling"] = "strong"
         if args.imgsz != 1024:
-            sec("image_size_1024_reference_default", imgsz=1024)
+            sec("image_size_1024_reference_default", imgsz=1024, det_batch=min(main_r.DB, 2))      # 4x the activations per item: keep the plan in memory
         if args.det_precision != "f32":
             sec("detector_exact_f32", det_precision="f32")
 
