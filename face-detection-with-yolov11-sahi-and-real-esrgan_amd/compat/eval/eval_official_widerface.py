@@ -44,17 +44,28 @@ class OfficialWiderFaceEvaluator:
         self.facebox_list, self.event_list, self.file_list = gt_mat["face_bbx_list"], gt_mat["event_list"], gt_mat["file_list"]
         self.setting_gts = {s: loadmat(self.gt_path / f"wider_{s}_val.mat")["gt_list"] for s in self.settings}
 
-    # ---- inference (:185-281), SAHI or plain predict; boxes as x, y, w, h, score -------------------------------------------------
+    def _get_slice_size_adaptive(self, w, h):
+        max_dim = max(w, h)
+        if max_dim > 2500:
+            return 512
+        if max_dim > 1500:
+            return 416
+        return 320
+
+    # ---- inference (:166-255), SAHI or plain predict; boxes as x, y, w, h, score -------------------------------------------------
     def _run_single_inference(self, img_path):
         from PIL import Image
         img = np.asarray(Image.open(img_path).convert("RGB"))
         if self.use_sahi:
             from sahi.predict import get_sliced_prediction
             cfg = dict(self.sahi_config)
-            if "slice_height" not in cfg:
-                raise NotImplementedError("adaptive slicing needs the reference's size heuristic; use slicing_strategy='uniform'")
-            res = get_sliced_prediction(img, self.detection_model, slice_height=cfg["slice_height"], slice_width=cfg["slice_width"],
-                                        overlap_height_ratio=cfg["overlap_ratio"], overlap_width_ratio=cfg["overlap_ratio"], postprocess_type="NMS", verbose=0)
+            if "slice_height" in cfg:
+                slice_h, slice_w = cfg["slice_height"], cfg["slice_width"]
+            else:                                                      # 'adaptive' (:196-198)
+                slice_h = slice_w = self._get_slice_size_adaptive(img.shape[1], img.shape[0])
+            res = get_sliced_prediction(img, self.detection_model, slice_height=slice_h, slice_width=slice_w, overlap_height_ratio=cfg["overlap_ratio"],
+                                        overlap_width_ratio=cfg["overlap_ratio"], postprocess_type="NMS", postprocess_match_threshold=0.5,
+                                        postprocess_class_agnostic=True, verbose=0)
             rows = [[*p.bbox.to_xywh(), p.score.value] for p in res.object_prediction_list]
         else:
             self.detection_model.perform_inference(img)

@@ -191,19 +191,39 @@ def enhance_face_crops_batch(crops_dir, enhancer, prefix="enhanced", progress_ca
 
 
 def create_enhancement_summary(results, output_path):
+    """The batch report in the reference's text layout (utils/enhancer.py:409-452), line for line (pinned by tests/golden/wrapper_expected.json)."""
+    import datetime
     st = results["statistics"]
-    with open(output_path, "w", encoding="utf-8") as fh:
-        fh.write("REAL-ESRGAN ENHANCEMENT SUMMARY\n" + "=" * 50 + "\n")
-        fh.write(f"Total files: {st['total_files']}\nSuccessful: {st['successful']}\nFailed: {st['failed']}\n")
-        if st["total_files"]:
-            fh.write(f"Success rate: {st['successful'] / st['total_files'] * 100:.1f}%\n")
-        fh.write(f"Total time: {st['total_time']:.2f} s\n\n")
-        for info in results["enhancement_info"]:
-            fh.write(f"{os.path.basename(info['original_path'])}: {info['original_size']} -> {info['enhanced_size']} (x{info['scale_factor']})\n")
-        for f in results["failed_files"]:
-            fh.write(f"FAILED: {os.path.basename(f)}\n")
+    n = max(st["total_files"], 1)
+    lines = ["", "=== LAPORAN ENHANCEMENT WAJAH ===", f"Generated: {datetime.datetime.now().strftime('%Y-%m-%d %H:%M:%S')}", "",
+             "--- RINGKASAN STATISTIK ---", f"Total File Diproses: {st['total_files']}", f" Berhasil: {st['successful']}", f" Gagal: {st['failed']}",
+             f" Tingkat Keberhasilan: {(st['successful'] / n * 100):.1f}%", f" Waktu Total: {st['total_time']:.2f} detik",
+             f" Waktu Rata-rata per File: {(st['total_time'] / n):.2f} detik", "", "--- DETAIL FILE BERHASIL ---"]
+    text = "\n".join(lines) + "\n"
+    for i, info in enumerate(results["enhancement_info"], 1):
+        o, e = info["original_size"], info["enhanced_size"]
+        text += (f"\nFile #{i}: {os.path.basename(info['original_path'])}\n   Ukuran Asli: {o[0]}x{o[1]} px\n   Ukuran Enhanced: {e[0]}x{e[1]} px\n"
+                 f"   Scale Factor: {info['scale_factor']}x\n   Output: {os.path.basename(info['output_path'])}\n")
+    if results["failed_files"]:
+        text += f"\n--- FILE GAGAL ({len(results['failed_files'])}) ---\n"
+        for i, f in enumerate(results["failed_files"], 1):
+            text += f"{i}. {os.path.basename(f)}\n"
+    try:
+        os.makedirs(os.path.dirname(output_path), exist_ok=True)
+        with open(output_path, "w", encoding="utf-8") as fh:
+            fh.write(text)
+        print(f" Enhancement summary saved to: {os.path.basename(output_path)}")
+    except Exception as e:
+        print(f" Error saving enhancement summary: {e}")
 
 
 def get_available_models():
-    return {"RealESRGAN_x4plus": {"scale": 4, "num_block": 23}, "RealESRGAN_x2plus": {"scale": 2, "num_block": 23},
-            "RealESRGAN_x4plus_anime_6B": {"scale": 4, "num_block": 6}}
+    """The reference's model table (utils/enhancer.py:454-480) plus `num_block`, which this build needs to lay the network out."""
+    return {
+        "RealESRGAN_x4plus": {"description": "Model utama untuk gambar natural (4x)", "scale": 4, "best_for": "Foto natural, potret, wajah", "file_size": "~65MB",
+                              "recommended_tile": 400, "num_block": 23},
+        "RealESRGAN_x2plus": {"description": "Model untuk enhancement 2x (lebih cepat)", "scale": 2, "best_for": "Enhancement ringan, GPU terbatas", "file_size": "~65MB",
+                              "recommended_tile": 600, "num_block": 23},
+        "RealESRGAN_x4plus_anime_6B": {"description": "Model khusus untuk anime/kartun (4x)", "scale": 4, "best_for": "Gambar anime, kartun, ilustrasi", "file_size": "~18MB",
+                                       "recommended_tile": 400, "num_block": 6},
+    }

@@ -7,7 +7,9 @@ Follows /root/reference/utils/yolo_wrapper.py:
   * `attach` — `attach_keypoints_to_predictions` (:168-200): exact key first, else the cache entry of highest IoU if that is > 0.5
     (strict), scanning the cache in insertion order (the first entry wins ties because only a strictly larger IoU replaces it);
   * `iou` — `_calculate_iou` (:202-217).
-The reference pulls box / keypoint arrays off torch tensors; here they are numpy arrays. Parity unpinned (oracle/__init__.py).
+The reference pulls box / keypoint arrays off torch tensors; here they are numpy arrays. `iou` and `attach` are PINNED: tests/test_wrapper_pinned.py
+checks them against the outputs of the reference's own methods on seeded inputs (tests/golden/make_wrapper_fixtures.py); `convert` needs sahi's
+ObjectPrediction, which is not in the tree, and stays unpinned.
 """
 from __future__ import annotations
 

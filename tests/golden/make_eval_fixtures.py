@@ -3,8 +3,9 @@
 The two evaluation modules cannot be imported here (cv2, seaborn, matplotlib, sahi, ultralytics are absent — ordinary ImportError), so this
 script parses the files, compiles ONLY the named methods from their syntax trees (unchanged, nothing added, no stand-in for a missing
 library) and calls them on seeded inputs:
-  /root/reference/eval/eval_dual.py               calculate_iou, calculate_average_precision, evaluate_single_set
-  /root/reference/eval/eval_official_widerface.py _voc_ap, _img_pr_info, _dataset_pr_info
+  /root/reference/eval/eval_dual.py               calculate_iou, calculate_average_precision, evaluate_single_set, map_subcategory_to_difficulty,
+                                                  get_slice_size_adaptive
+  /root/reference/eval/eval_official_widerface.py _voc_ap, _img_pr_info, _dataset_pr_info, _get_slice_size_adaptive
 `evaluate_single_set` is driven through a plain object that carries the attributes the method reads (ground truth, thresholds) and whose
 `run_inference` returns the seeded predictions — inputs, not arithmetic. `_image_eval` / `_evaluate_setting` call the Cython `bbox_overlaps`
 that is not in the tree and are NOT run. Needs /root/reference; run here, never on the GPU box. Only data is written (inputs + outputs).
@@ -57,8 +58,17 @@ def random_image(rng, n_faces, n_pred, integer):
 def main():
     rng = np.random.default_rng(20250607)
     out = {}
-    Dual = methods_of(REF / "eval_dual.py", "DualWiderFaceEvaluator", ["calculate_iou", "calculate_average_precision", "evaluate_single_set"])
-    Off = methods_of(REF / "eval_official_widerface.py", "OfficialWiderFaceEvaluator", ["_voc_ap", "_img_pr_info", "_dataset_pr_info"])
+    Dual = methods_of(REF / "eval_dual.py", "DualWiderFaceEvaluator", ["calculate_iou", "calculate_average_precision", "evaluate_single_set",
+                                                                        "map_subcategory_to_difficulty", "get_slice_size_adaptive"])
+    Off = methods_of(REF / "eval_official_widerface.py", "OfficialWiderFaceEvaluator", ["_voc_ap", "_img_pr_info", "_dataset_pr_info", "_get_slice_size_adaptive"])
+    dd, oo = Dual.__new__(Dual), Off.__new__(Off)
+    dims = [(640, 480), (1500, 1500), (1501, 900), (2500, 100), (2501, 2000), (4160, 2340), (100, 2600)]
+    out["adaptive_dims"] = np.asarray(dims, np.int64)
+    out["adaptive_dual"] = np.asarray([dd.get_slice_size_adaptive(w, h) for w, h in dims], np.int64)
+    out["adaptive_official"] = np.asarray([oo._get_slice_size_adaptive(w, h) for w, h in dims], np.int64)
+    subcats = ["large_clear", "large_degraded", "medium_clear", "medium_degraded", "small_clear", "small_degraded"]
+    order = ["easy", "medium", "hard"]
+    out["difficulty_map"] = np.asarray([[int(d in dd.map_subcategory_to_difficulty(c)) for d in order] for c in subcats], np.int64)
 
     # ---- eval_dual: IoU pairs
     d = Dual.__new__(Dual)

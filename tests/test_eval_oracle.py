@@ -67,3 +67,17 @@ def test_bbox_overlaps_and_image_eval_micro_cases():
     assert rec.tolist() == [1, 1, 2, 2] and prop.tolist() == [1, 1, 1, 1]
     ap, recall, prec, counts, n = R.evaluate_setting([{"pred": pred, "gt": gt, "keep": np.asarray([1, 2])}], 10, 0.5)
     assert n == 2 and counts[0].tolist() == [1, 1] and counts[3].tolist() == [4, 2] and recall[-1] == 1.0 and prec[-1] == 0.5
+
+
+def test_adaptive_slice_size_and_difficulty_map_match_reference(fx):
+    """The drop-in evaluator classes (compat/eval) against the reference's own helper outputs."""
+    import ffp_amd.compat
+    ffp_amd.compat.install()
+    from eval.eval_dual import DualWiderFaceEvaluator
+    from eval.eval_official_widerface import OfficialWiderFaceEvaluator
+    o = OfficialWiderFaceEvaluator.__new__(OfficialWiderFaceEvaluator)
+    assert [o._get_slice_size_adaptive(int(w), int(h)) for w, h in fx["adaptive_dims"]] == fx["adaptive_official"].tolist() == fx["adaptive_dual"].tolist()
+    d = DualWiderFaceEvaluator(subcategory_gt={})
+    subcats = ["large_clear", "large_degraded", "medium_clear", "medium_degraded", "small_clear", "small_degraded"]
+    got = [[int(x in d.map_subcategory_to_difficulty(c)) for x in ("easy", "medium", "hard")] for c in subcats]
+    assert got == fx["difficulty_map"].tolist()
