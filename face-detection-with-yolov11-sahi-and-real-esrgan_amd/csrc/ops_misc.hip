@@ -540,8 +540,12 @@ __global__ void __launch_bounds__(256) stem_from_frame_kernel(const uint8_t* __r
                                                               T* __restrict__ out, int out_cs, int out_coff, const float* __restrict__ w,
                                                               const float* __restrict__ bias, int stride, int act, const int4* __restrict__ in_tab,
                                                               const int4* __restrict__ out_tab, int n_img, long long total_out_px) {
-  __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
-  for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = w[i];
+  // The 27 x COUT weights are read at compile-time offsets from the (wave-uniform) kernel argument: hipcc turns that into scalar
+  // loads and the multiply-adds take the weight as their SGPR operand — no LDS copy of the weights, no LDS read per four FMAs
+  // (the LDS-broadcast form spent half its issue slots on ds_read_b128).
+  // q / 255 for the 256 possible sample values, rounded exactly as the division the two-kernel path performs (through T)
+  __shared__ float norm[256];
+  norm[threadIdx.x] = (float)(T)((float)threadIdx.x / 255.0f);
   __syncthreads();
   const long long gp = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gp >= total_out_px) return;
@@ -553,25 +557,20 @@ __global__ void __launch_bounds__(256) stem_from_frame_kernel(const uint8_t* __r
 #pragma unroll
   for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
 #pragma unroll 1
-  for (int tap = 0; tap < 9; ++tap) {
+  for (int tap = 0; tap < 9; ++tap) {                  // one tap = 3 x COUT weights live in scalar registers at a time
     const int ky = tap / 3, kx = tap - ky * 3;
     const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
     float px[3] = {0.f, 0.f, 0.f};
     if ((unsigned)iy < (unsigned)ti.y && (unsigned)ix < (unsigned)ti.z) {
       int q[3];
       letterbox_sample(frame, W, L, iy, ix, q);
-      // through T: the two-kernel path stores the normalised pixel in the activation type
-      px[0] = (float)(T)((float)q[flip ? 2 : 0] / 255.0f); px[1] = (float)(T)((float)q[1] / 255.0f); px[2] = (float)(T)((float)q[flip ? 0 : 2] / 255.0f);
+      px[0] = norm[q[flip ? 2 : 0] & 255]; px[1] = norm[q[1] & 255]; px[2] = norm[q[flip ? 0 : 2] & 255];
     }
-    const float* wt = ws + tap * 3 * COUT;
+    const float* wt = w + tap * 3 * COUT;
 #pragma unroll
     for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-      for (int c = 0; c < COUT; c += 4) {
-        const float4 k = *reinterpret_cast<const float4*>(wt + ci * COUT + c);
-        acc[c] = fmaf(px[ci], k.x, acc[c]); acc[c + 1] = fmaf(px[ci], k.y, acc[c + 1]);
-        acc[c + 2] = fmaf(px[ci], k.z, acc[c + 2]); acc[c + 3] = fmaf(px[ci], k.w, acc[c + 3]);
-      }
+      for (int c = 0; c < COUT; ++c) acc[c] = fmaf(px[ci], wt[ci * COUT + c], acc[c]);
   }
   T* op = out + (size_t)gp * out_cs + out_coff;
 #pragma unroll
