@@ -580,6 +580,80 @@ __global__ void __launch_bounds__(256) stem_from_frame_kernel(const uint8_t* __r
   }
 }
 
+// Depthwise 3x3 as a walk down the image: a thread owns 4 columns x 4 channels of an RB-row x 16-column tile and slides a three-row
+// window over it — six 16-byte loads per output row of four pixels (1.5 loads per output) instead of the strip kernel's eighteen per
+// four outputs; everything else (weights, bias, activation, residual, max-|value|) as in dwconv_strip_body.
+template <typename T, int RB>
+__global__ void __launch_bounds__(256) dwconv3x3_col_kernel(const T* __restrict__ in, int in_cs, int in_coff, int grp, int grp_stride, int grp_off,
+                                                            T* __restrict__ out, int out_cs, int out_coff, const float* __restrict__ w /*[9][C]*/,
+                                                            const float* __restrict__ bias, const T* __restrict__ res, int r_cs, int r_coff, int C, int act,
+                                                            const int4* __restrict__ tab, const int4* __restrict__ tiles, int n_tiles, unsigned* __restrict__ amax) {
+  const int C4 = C >> 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  float mx = 0.f;
+  if (idx < (long long)n_tiles * 4 * C4) {
+    const int c = (int)(idx % C4) * 4;
+    const int strip = (int)((idx / C4) & 3);
+    const int4 tl = tiles[idx / (4 * C4)];
+    const int4 t = tab[tl.x];
+    const int Hh = t.y, Ww = t.z, x0 = tl.z + 4 * strip, y0 = tl.y;
+    if (x0 < Ww) {
+      const int cin = in_coff + (c / grp) * grp_stride + grp_off + (c % grp);
+      float4 k[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) k[i] = *reinterpret_cast<const float4*>(w + i * C + c);
+      const float4 b = *reinterpret_cast<const float4*>(bias + c);
+      const T* ibase = in + (size_t)t.x * in_cs + cin;
+      auto load_row = [&](int yy, float4 (&r)[6]) {
+        const bool rok = (unsigned)yy < (unsigned)Hh;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int xx = x0 + j - 1;
+          r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (rok && (unsigned)xx < (unsigned)Ww) r[j] = ld4<T>(ibase + ((size_t)yy * Ww + xx) * in_cs);
+        }
+      };
+      float4 v[3][6];
+      load_row(y0 - 1, v[0]);
+      load_row(y0, v[1]);
+      const int rows = min(RB, Hh - y0);
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        if (r < rows) {
+          load_row(y0 + r + 1, v[(r + 2) % 3]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (x0 + i < Ww) {
+              float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+              for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                  const float4 a = v[(r + ky) % 3][i + kx], q = k[ky * 3 + kx];
+                  acc.x = fmaf(a.x, q.x, acc.x); acc.y = fmaf(a.y, q.y, acc.y); acc.z = fmaf(a.z, q.z, acc.z); acc.w = fmaf(a.w, q.w, acc.w);
+                }
+              const long long gp = (long long)t.x + (long long)(y0 + r) * Ww + x0 + i;
+              float4 o = make_float4(act_fn(acc.x + b.x, act), act_fn(acc.y + b.y, act), act_fn(acc.z + b.z, act), act_fn(acc.w + b.w, act));
+              if (res) {
+                const float4 rr = ld4<T>(res + (size_t)gp * r_cs + r_coff + c);
+                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+              }
+              mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+              st4<T>(out + (size_t)gp * out_cs + out_coff + c, o);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const unsigned bb = __float_as_uint(mx);
+    if ((threadIdx.x & 63) == 0 && bb > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, bb);
+  }
+}
+
 inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 }  // namespace
@@ -642,6 +716,25 @@ void launch_dwconv(const DwConvOp& op, hipStream_t st) {
                 op.out.coff % 4 == 0 && (!op.has_res || (op.res.cs % 4 == 0 && op.res.coff % 4 == 0)),
             FFP_ERR_ARG, "dwconv %s: channel counts/offsets must be multiples of 4", pc.name.c_str());
   const int4* tab = op.out.lvl->d_tab.as<int4>();
+  static const bool col_walk = [] { const char* e = getenv("FFP_DW_STRIP"); return !(e && e[0] == '1'); }();      // FFP_DW_STRIP=1: the strip kernel (A/B aid)
+  if (col_walk && !op.out.lvl->capacity()) {
+    constexpr int RB = 8;
+    int n_tiles = 0;
+    const int* d_count = nullptr;
+    const int4* tiles = op.out.lvl->tile_table(RB, &n_tiles, &d_count, st);
+    const unsigned nbc = blocks_for((long long)n_tiles * 4 * (C / 4), 256);
+    if (nbc == 0) return;
+    if (op.in.dt == F32)
+      hipLaunchKernelGGL((dwconv3x3_col_kernel<float, RB>), dim3(nbc), dim3(256), 0, st, (const float*)op.in.ptr, op.in.cs, op.in.coff, grp, gstride, op.grp_off,
+                         (float*)op.out.ptr, op.out.cs, op.out.coff, pc.w.as<float>(), pc.bias.as<float>(), op.has_res ? (const float*)op.res.ptr : nullptr,
+                         op.res.cs, op.res.coff, C, op.act, tab, tiles, n_tiles, op.out.amax);
+    else
+      hipLaunchKernelGGL((dwconv3x3_col_kernel<_Float16, RB>), dim3(nbc), dim3(256), 0, st, (const _Float16*)op.in.ptr, op.in.cs, op.in.coff, grp, gstride,
+                         op.grp_off, (_Float16*)op.out.ptr, op.out.cs, op.out.coff, pc.w.as<float>(), pc.bias.as<float>(),
+                         op.has_res ? (const _Float16*)op.res.ptr : nullptr, op.res.cs, op.res.coff, C, op.act, tab, tiles, n_tiles, op.out.amax);
+    FFP_HIP(hipGetLastError());
+    return;
+  }
   const unsigned nb = blocks_for(((op.out.lvl->total_px + 3) / 4) * (C / 4), 256);
   if (op.in.dt == F32)
     hipLaunchKernelGGL(dwconv3x3_strip_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)op.in.ptr, op.in.cs, op.in.coff, grp,
