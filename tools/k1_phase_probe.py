@@ -6,9 +6,9 @@ from ffp_amd import _lib
 
 N = 122
 LAYERS = [("model.4.cv2", 64, 192, 256), ("model.9.cv2", 16, 1024, 512), ("model.8.cv1", 16, 512, 512), ("model.22.cv1", 16, 768, 512), ("model.6.cv2", 32, 384, 256), ("model.13.cv1", 32, 768, 256)]
-names = {0: "wide", 1: "wideH", 2: "narrow2", 16: "pw1x4s", 18: "wide8"}
+names = {0: "wide", 1: "wideH", 2: "narrow2", 16: "pw1x4s"}
 for name, hw, cin, cout in LAYERS:
-    for shape in (0, 1, 18, 16):
+    for shape in (0, 1, 2, 16):
         row = []
         for dbg, tag in ((0, "full"), (1, "-store"), (2, "-mfma"), (8, "-stash"), (4, "-refetch"), (3, "-store-mfma"), (11, "-store-mfma-stash")):
             if shape == 16 and dbg:
