@@ -22,27 +22,24 @@ class DualWiderFaceEvaluator:
         self.predictions = predictions or {}
         self.iou_threshold, self.global_confidence = iou_threshold, global_confidence
 
+    _DIFFICULTY = {"large_clear": ["easy", "medium", "hard"], "large_degraded": ["medium", "hard"], "medium_clear": ["medium", "hard"]}
+
     def map_subcategory_to_difficulty(self, category):
-        difficulties = []
-        if category == "large_clear":
-            difficulties.append("easy")
-        if category in ["large_clear", "large_degraded", "medium_clear"]:
-            difficulties.append("medium")
-        difficulties.append("hard")
-        return difficulties
+        """Which WIDER difficulty sets a sub-category counts towards (:317-332): everything is 'hard', three of them also 'medium', one 'easy'."""
+        return list(self._DIFFICULTY.get(category, ["hard"]))
 
     def calculate_average_precision(self, all_detections, total_gt):
+        """11-point interpolated AP (:293-315). The detections are ordered by a STABLE descending sort on confidence, like list.sort(reverse=True)."""
         if total_gt == 0 or not all_detections:
             return 0.0
-        all_detections.sort(key=lambda x: x["confidence"], reverse=True)
-        tp_cumsum = np.cumsum([d["is_tp"] for d in all_detections])
-        fp_cumsum = np.cumsum([not d["is_tp"] for d in all_detections])
-        recalls = tp_cumsum / total_gt
-        precisions = tp_cumsum / (tp_cumsum + fp_cumsum)
+        all_detections.sort(key=lambda det: det["confidence"], reverse=True)
+        hit = np.fromiter((bool(det["is_tp"]) for det in all_detections), dtype=bool, count=len(all_detections))
+        tp, fp = np.cumsum(hit), np.cumsum(~hit)
+        recall, precision = tp / total_gt, tp / (tp + fp)
         ap = 0.0
-        for t in np.arange(0., 1.1, 0.1):
-            p = 0 if np.sum(recalls >= t) == 0 else np.max(precisions[recalls >= t])
-            ap += p / 11.0
+        for level in np.arange(0., 1.1, 0.1):
+            reached = recall >= level
+            ap += (np.max(precision[reached]) if reached.any() else 0) / 11.0
         return ap
 
     def evaluate_single_set(self, category_type, category_name, valid_categories):

@@ -86,12 +86,12 @@ class OfficialWiderFaceEvaluator:
 
     # ---- evaluation --------------------------------------------------------------------------------------------------------------
     def _voc_ap(self, rec, prec):
-        mrec = np.concatenate(([0.], rec, [1.]))
-        mpre = np.concatenate(([0.], prec, [0.]))
-        for i in range(mpre.size - 1, 0, -1):
-            mpre[i - 1] = np.maximum(mpre[i - 1], mpre[i])
-        i = np.where(mrec[1:] != mrec[:-1])[0]
-        return np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
+        """Area under the monotone precision envelope (:282-300), vectorised: running maximum from the right, summed over recall steps."""
+        r = np.concatenate(([0.0], np.asarray(rec, np.float64), [1.0]))
+        p = np.concatenate(([0.0], np.asarray(prec, np.float64), [0.0]))
+        env = np.maximum.accumulate(p[::-1])[::-1]
+        step = np.flatnonzero(r[1:] != r[:-1])
+        return np.sum((r[step + 1] - r[step]) * env[step + 1])
 
     def _dataset_pr_info(self, pr_curve, count_face):
         out = np.zeros((self.thresh_num, 2))

@@ -81,3 +81,20 @@ def test_adaptive_slice_size_and_difficulty_map_match_reference(fx):
     subcats = ["large_clear", "large_degraded", "medium_clear", "medium_degraded", "small_clear", "small_degraded"]
     got = [[int(x in d.map_subcategory_to_difficulty(c)) for x in ("easy", "medium", "hard")] for c in subcats]
     assert got == fx["difficulty_map"].tolist()
+
+
+@pytest.mark.parametrize("k", range(5))
+def test_compat_ap11_and_voc_ap_match_reference(fx, k):
+    """The shipped evaluator classes' host-side arithmetic (vectorised) against the reference's own outputs."""
+    import ffp_amd.compat
+    ffp_amd.compat.install()
+    from eval.eval_dual import DualWiderFaceEvaluator
+    from eval.eval_official_widerface import OfficialWiderFaceEvaluator
+    d = DualWiderFaceEvaluator(subcategory_gt={})
+    dets = [{"confidence": float(c), "is_tp": bool(t)} for c, t in zip(fx[f"ap11_{k}_conf"], fx[f"ap11_{k}_tp"])]
+    assert d.calculate_average_precision(dets, int(fx[f"ap11_{k}_total"])) == float(fx[f"ap11_{k}_out"])
+    if k < 4:
+        o = OfficialWiderFaceEvaluator.__new__(OfficialWiderFaceEvaluator)
+        o.thresh_num = int(fx[f"pr_{k}_T"])
+        assert o._voc_ap(fx[f"ap_{k}_rec"], fx[f"ap_{k}_prec"]) == float(fx[f"ap_{k}_out"])
+        assert np.array_equal(o._dataset_pr_info(fx[f"dpr_{k}_counts"], int(fx[f"dpr_{k}_faces"])), fx[f"dpr_{k}_out"])
