@@ -614,13 +614,10 @@ int ffp_jpeg_decode_dev(int device, const uint8_t* data, int64_t n, int bgr, uin
   int ndev = 0;
   FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "jpeg_decode: no HIP device %d (no CPU path)", device);
   FFP_HIP(hipSetDevice(device));
-  JpegScan s;
-  jpeg_entropy_decode(data, n, s, false);
-  FFP_CHECK(row_stride >= (int64_t)s.w * 3 && cap >= row_stride * (s.h - 1) + (int64_t)s.w * 3, FFP_ERR_ARG, "jpeg_decode: output buffer too small for %dx%d", s.w, s.h);
   hipStream_t st;
   FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   try {
-    jpeg_reconstruct_device(s, d_out, row_stride, bgr, st);
+    jpeg_decode_to_device(data, n, d_out, row_stride, cap, bgr, st, nullptr, nullptr);
   } catch (...) {
     (void)hipStreamDestroy(st);
     throw;
@@ -636,14 +633,14 @@ int ffp_jpeg_decode(int device, const uint8_t* data, int64_t n, int bgr, uint8_t
   FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "jpeg_decode: no HIP device %d (no CPU path)", device);
   FFP_HIP(hipSetDevice(device));
   JpegScan s;
-  jpeg_entropy_decode(data, n, s, false);
+  jpeg_entropy_decode(data, n, s, true);
   const size_t bytes = (size_t)s.h * s.w * 3;
   FFP_CHECK(cap >= (int64_t)bytes, FFP_ERR_ARG, "jpeg_decode: output buffer too small for %dx%d", s.w, s.h);
   DevBuf d(bytes);
   hipStream_t st;
   FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   try {
-    jpeg_reconstruct_device(s, d.as<unsigned char>(), (long long)s.w * 3, bgr, st);
+    jpeg_decode_to_device(data, n, d.as<unsigned char>(), 0, (long long)bytes, bgr, st, nullptr, nullptr);
   } catch (...) {
     (void)hipStreamDestroy(st);
     throw;

@@ -654,25 +654,73 @@ __global__ void jpeg_colour_kernel(const unsigned char* __restrict__ py, const u
 
 }  // namespace
 
-void jpeg_reconstruct_device(const JpegScan& s, unsigned char* d_out, long long stride, int bgr, hipStream_t st) {
-  DevBuf coef[3], plane[3], qt(sizeof(unsigned short) * 64 * 4);
-  FFP_HIP(hipMemcpyAsync(qt.p, s.qt, sizeof(unsigned short) * 64 * 4, hipMemcpyHostToDevice, st));
+void JpegDecodeWs::ensure(const JpegScan& s) {
+  if (!qt.p) qt = DevBuf(sizeof(unsigned short) * 64 * 4);
+  for (int c = 0; c < s.ncomp; ++c) {
+    const size_t nb = (size_t)s.comp[c].blocks_x * s.comp[c].blocks_y;
+    if (nb > cap[c]) {
+      cap[c] = nb * 5 / 4 + 64;
+      host[c].ensure(cap[c] * 64 * sizeof(short));
+      dev[c] = DevBuf(cap[c] * 64 * sizeof(short));
+      plane[c] = DevBuf(cap[c] * 64 + 16);
+    }
+    const_cast<JpegScan&>(s).coef[c] = static_cast<short*>(host[c].p);
+  }
+}
+
+namespace {
+std::mutex g_dec_mu;
+std::vector<JpegDecodeWs*> g_dec_free;
+}  // namespace
+
+JpegDecodeWs* jpeg_ws_acquire() {
+  std::lock_guard<std::mutex> lock(g_dec_mu);
+  if (g_dec_free.empty()) return new JpegDecodeWs();
+  JpegDecodeWs* w = g_dec_free.back();
+  g_dec_free.pop_back();
+  return w;
+}
+
+void jpeg_ws_release(JpegDecodeWs* ws) {
+  std::lock_guard<std::mutex> lock(g_dec_mu);
+  g_dec_free.push_back(ws);                          // (kept for the life of the process: a handful of frames' worth of staging)
+}
+
+void jpeg_reconstruct_device(const JpegScan& s, JpegDecodeWs& ws, unsigned char* d_out, long long stride, int bgr, hipStream_t st) {
+  FFP_HIP(hipMemcpyAsync(ws.qt.p, s.qt, sizeof(unsigned short) * 64 * 4, hipMemcpyHostToDevice, st));
   for (int c = 0; c < s.ncomp; ++c) {
     const JpegComp& cp = s.comp[c];
     const int nb = cp.blocks_x * cp.blocks_y;
-    coef[c] = DevBuf((size_t)nb * 64 * sizeof(short));
-    plane[c] = DevBuf((size_t)nb * 64 + 16);
-    FFP_HIP(hipMemcpyAsync(coef[c].p, s.coef[c].data(), (size_t)nb * 64 * sizeof(short), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nb + 7) / 8), dim3(64), 0, st, coef[c].as<short>(), nb, cp.blocks_x, qt.as<unsigned short>() + 64 * cp.tq,
-                       plane[c].as<unsigned char>());
+    FFP_HIP(hipMemcpyAsync(ws.dev[c].p, s.coef[c], (size_t)nb * 64 * sizeof(short), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nb + 7) / 8), dim3(64), 0, st, ws.dev[c].as<short>(), nb, cp.blocks_x, ws.qt.as<unsigned short>() + 64 * cp.tq,
+                       ws.plane[c].as<unsigned char>());
   }
   const int hsub = s.ncomp == 3 ? s.hmax : 1, vsub = s.ncomp == 3 ? s.vmax : 1;
   const int ch = (s.h + vsub - 1) / vsub, cw = (s.w + hsub - 1) / hsub;
-  hipLaunchKernelGGL(jpeg_colour_kernel, dim3((s.w + 255) / 256, s.h), dim3(256), 0, st, plane[0].as<unsigned char>(),
-                     s.ncomp == 3 ? plane[1].as<unsigned char>() : nullptr, s.ncomp == 3 ? plane[2].as<unsigned char>() : nullptr, s.h, s.w,
+  hipLaunchKernelGGL(jpeg_colour_kernel, dim3((s.w + 255) / 256, s.h), dim3(256), 0, st, ws.plane[0].as<unsigned char>(),
+                     s.ncomp == 3 ? ws.plane[1].as<unsigned char>() : nullptr, s.ncomp == 3 ? ws.plane[2].as<unsigned char>() : nullptr, s.h, s.w,
                      s.comp[0].blocks_x * 8, s.ncomp == 3 ? s.comp[1].blocks_x * 8 : 0, ch, cw, hsub, vsub, s.ncomp, bgr, stride, d_out);
   FFP_HIP(hipGetLastError());
-  FFP_HIP(hipStreamSynchronize(st));                   // the staging buffers die with this frame
+  FFP_HIP(hipStreamSynchronize(st));                   // the staging planes go back to the pool after this
+}
+
+void jpeg_decode_to_device(const unsigned char* data, long long n, unsigned char* d_out, long long stride, long long cap, int bgr, hipStream_t st, int* out_h, int* out_w) {
+  JpegScan s;
+  jpeg_entropy_decode(data, n, s, true);
+  if (out_h) *out_h = s.h;
+  if (out_w) *out_w = s.w;
+  if (stride == 0) stride = (long long)s.w * 3;
+  FFP_CHECK(stride >= (long long)s.w * 3 && cap >= stride * (s.h - 1) + (long long)s.w * 3, FFP_ERR_ARG, "jpeg_decode: output buffer too small for %dx%d", s.w, s.h);
+  JpegDecodeWs* ws = jpeg_ws_acquire();
+  try {
+    ws->ensure(s);
+    jpeg_entropy_decode(data, n, s, false);
+    jpeg_reconstruct_device(s, *ws, d_out, stride, bgr, st);
+  } catch (...) {
+    jpeg_ws_release(ws);
+    throw;
+  }
+  jpeg_ws_release(ws);
 }
 
 }  // namespace ffp

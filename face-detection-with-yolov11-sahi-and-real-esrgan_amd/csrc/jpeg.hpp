@@ -24,12 +24,24 @@ struct JpegScan {
   int h = 0, w = 0, ncomp = 0, hmax = 1, vmax = 1;
   JpegComp comp[3];
   unsigned short qt[4][64];                     // natural order
-  std::vector<short> coef[3];                   // [blocks_y][blocks_x][64] natural order, quantised
+  short* coef[3] = {nullptr, nullptr, nullptr}; // [blocks_y][blocks_x][64] natural order, quantised: caller's (pinned) memory, zeroed by the decoder
 };
+// staging of one decode in flight: pinned host coefficient planes (the entropy decoder writes them, the copies to the device run at
+// full PCIe rate) and their device twins + sample planes; kept in a pool so that concurrent decodes neither allocate nor free
+struct JpegDecodeWs {
+  HostPinned host[3];
+  DevBuf dev[3], plane[3], qt;
+  size_t cap[3] = {0, 0, 0};
+  void ensure(const JpegScan& s);               // sizes everything for the scan and points s.coef at the pinned planes
+};
+JpegDecodeWs* jpeg_ws_acquire();
+void jpeg_ws_release(JpegDecodeWs* ws);
 // markers + Huffman decoding of a baseline / extended-sequential 8-bit JFIF file (one interleaved scan, 1 or 3 components, chroma
 // at full, half-width or half-width-half-height resolution; restart intervals). Throws ffp::Error on anything else.
 void jpeg_entropy_decode(const unsigned char* data, long long n, JpegScan& out, bool header_only);
 // dequantisation + integer IDCT + upsampling + colour conversion into d_out (h x w x 3 uint8, row pitch `stride`, RGB or BGR)
-void jpeg_reconstruct_device(const JpegScan& s, unsigned char* d_out, long long stride, int bgr, hipStream_t st);
+void jpeg_reconstruct_device(const JpegScan& s, JpegDecodeWs& ws, unsigned char* d_out, long long stride, int bgr, hipStream_t st);
+// header -> workspace -> entropy decode -> reconstruction, for a stream of `n` bytes (the three entry points of api.cpp share it)
+void jpeg_decode_to_device(const unsigned char* data, long long n, unsigned char* d_out, long long stride, long long cap, int bgr, hipStream_t st, int* out_h, int* out_w);
 
 }  // namespace ffp

@@ -166,7 +166,10 @@ void jpeg_entropy_decode(const unsigned char* d, long long n, JpegScan& out, boo
   const int mx = (out.w + 8 * out.hmax - 1) / (8 * out.hmax), my = (out.h + 8 * out.vmax - 1) / (8 * out.vmax);
   for (int c = 0; c < out.ncomp; ++c) { out.comp[c].blocks_x = mx * out.comp[c].hs; out.comp[c].blocks_y = my * out.comp[c].vs; }
   if (header_only) return;
-  for (int c = 0; c < out.ncomp; ++c) out.coef[c].assign((size_t)out.comp[c].blocks_x * out.comp[c].blocks_y * 64, 0);
+  for (int c = 0; c < out.ncomp; ++c) {
+    FFP_CHECK(out.coef[c] != nullptr, FFP_ERR_STATE, "jpeg: no coefficient plane for component %d", c);
+    std::memset(out.coef[c], 0, (size_t)out.comp[c].blocks_x * out.comp[c].blocks_y * 64 * sizeof(short));
+  }
   BitReader br{d + i, d + n};
   int last[3] = {0, 0, 0};
   long long count = 0;
@@ -180,7 +183,7 @@ void jpeg_entropy_decode(const unsigned char* d, long long n, JpegScan& out, boo
         const HuffTab& ta = ac[cp.ta];
         for (int dy = 0; dy < cp.vs; ++dy)
           for (int dx = 0; dx < cp.hs; ++dx) {
-            short* blk = out.coef[c].data() + ((size_t)(yy * cp.vs + dy) * cp.blocks_x + xx * cp.hs + dx) * 64;
+            short* blk = out.coef[c] + ((size_t)(yy * cp.vs + dy) * cp.blocks_x + xx * cp.hs + dx) * 64;
             const int sdc = br.symbol(td);
             FFP_CHECK(sdc <= 11, FFP_ERR_ARG, "jpeg: bad DC category");
             last[c] += br.receive_extend(sdc);
