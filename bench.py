@@ -149,14 +149,14 @@ class Runner:
         self.host_sr = None
         self.copy_stream = torch.cuda.Stream(device=self.dev)
         # jpeg_io: the reference's file boundaries inside the span (reported separately, never the headline) — every frame
-        # arrives as a JPEG stream and is decoded straight into its device slot (host Huffman decoding on a small thread pool, the rest
+        # arrives as a JPEG stream and is decoded straight into its device slot (host Huffman decoding on a thread pool of 8, the rest
         # on the device: no 24.9 MB upload), every SR batch leaves as JPEG files encoded from the device buffer (quality 95, like cv2.imwrite)
         self.jpeg_io = jpeg_io
         if jpeg_io:
             from concurrent.futures import ThreadPoolExecutor
             self._lib = _lib
             self.jpegs = [_lib.jpeg_encode(f, 95, bgr=False) for f in ctx["host_frames"]]
-            self.pool = ThreadPoolExecutor(max_workers=4)
+            self.pool = ThreadPoolExecutor(max_workers=8)
             self.jpeg_bytes_in = self.jpeg_bytes_out = 0
         self.host_supers, self.slots = {}, {}
         self.state, self.pending, self.queue, self.group = {}, {}, [], {}
