@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", action="store_true", help="CPU baseline on a bounded sample (3 slices + 3 crops) instead of one whole frame")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--secondary-steps", type=int, default=8)
+    ap.add_argument("--secondary-steps", type=int, default=20)
     return ap.parse_args()
 
 
@@ -410,7 +410,7 @@ def main():
     main_state = dict(main_r.state)
     main_sr_px = main_r.sr_px
 
-    # ---- secondary rows, measured in this same run (fewer steps): what the headline configuration is NOT ------------------------
+    # ---- secondary rows, measured in this same run (--secondary-steps, default 20 like the headline): what the headline configuration is NOT ------------------------
     secondary = {}
     if not args.no_secondary:
         ss, sw = max(2, args.secondary_steps), max(2, min(args.warmup, 4))

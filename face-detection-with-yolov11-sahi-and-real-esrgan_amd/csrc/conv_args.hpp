@@ -39,6 +39,17 @@ struct ConvArgs {
   int ntiles_host;          // tile-loop kernels (conv_rows16.hip): tiles of an exact-mode launch (the grid no longer says)
   const int* n_tiles_dev;   // capacity-mode levels (Level::reserve): the batch's tile count lives in device memory and the grid is
                             // sized for the capacity — workgroups past n_tiles * n_nblk exit; nullptr: the grid is exact
+  // stem-fused loader (conv_mfma_kernel<..., STEM = true>, launch_stem_conv): the conv's input is never stored — every workgroup
+  // computes its halo tile of the image-input conv (model.0: 3x3 stride 2 + SiLU over the letterboxed u8 frame) on the matrix
+  // cores and writes it straight into the LDS stage as split fp16 records
+  const unsigned char* st_frame;     // HxWx3 u8
+  const LetterboxImg* st_imgs;       // per item
+  const int4* st_tab;                // level table of the letterboxed network images (.y rows, .z columns)
+  const void* st_w;                  // stem weights as MFMA A fragments [chunk][hi|lo][64 lanes] x 16 B (stem_pack_kernel)
+  const float* st_bias;
+  int st_W;                          // frame width
+  int st_bytes;                      // frame size in bytes (range check of the loader's dword reads)
+  float st_scale;                    // 1 / (power of two the packed stem weights were multiplied by)
 };
 
 // (logical workgroup id, number of live workgroups) for a tile kernel; live == 0: this workgroup has nothing to do

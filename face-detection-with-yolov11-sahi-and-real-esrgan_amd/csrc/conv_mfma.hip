@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "conv_args.hpp"
+#include "letterbox.hpp"
 
 #ifndef FFP_SINGLE_STAGE
 #define FFP_SINGLE_STAGE 1     // tuning switch: 0 = always double-buffer the LDS stage
@@ -143,7 +144,9 @@ template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int K
 // Main loop: per chunk of KC input channels the input halo tile AND the chunk's weight fragments live in one LDS stage;
 // chunk c+1 is fetched global->registers while chunk c is multiplied out of LDS (no global access inside the MFMA
 // loop), then written to the other stage: one barrier per chunk.
-template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int KC>
+// STEM = true (one instantiation, launch_stem_conv): the input tensor does not exist — the loader computes the halo tile of the
+// image-input conv from the u8 frame (see ConvArgs::st_frame) and writes the split records itself.
+template <typename T, int KS, int STRIDE, int WM, int WN, int MI, int NIW, int KC, bool STEM = false>
 __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>::OCC)) conv_mfma_kernel(const ConvArgs a) {
   using G = Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>;
   using GT = typename G::GT;
@@ -221,7 +224,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
   for (int i = 0; i < RI; ++i) {
     const int idx = tid + i * 256;
     isrc[i] = OOB; ivec[i] = 0;
-    if (idx < G::NVI) {
+    if (!STEM && idx < G::NVI) {
       const int hp = idx / VPP;
       ivec[i] = idx % VPP;
       long long rel;
@@ -270,7 +273,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
   auto fetch = [&](int c0, uint4 (&qi)[RI], uint4 (&qw)[RW]) {
     const bool from_up = KS == 1 && c0 < a.up_c;          // chunk-uniform: up_c is a multiple of every chunk size
 #pragma unroll
-    for (int i = 0; i < RI; ++i) {
+    for (int i = 0; i < (STEM ? 0 : RI); ++i) {
       const int c = c0 + ivec[i] * EPV;
       if constexpr (KS == 1) {
         unsigned so = isrc[i];
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
   };
   auto stash = [&](unsigned char* buf, const uint4 (&qi)[RI], const uint4 (&qw)[RW]) {
 #pragma unroll
-    for (int i = 0; i < RI; ++i) {
+    for (int i = 0; i < (STEM ? 0 : RI); ++i) {
       const int idx = tid + i * 256;
       if (idx < G::NVI) {
         if (SPLIT) {   // 4 floats -> 4 fp16 hi parts + 4 fp16 residuals, stored in the hi / lo halves of the pixel record
@@ -306,6 +309,149 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
     for (int i = 0; i < RW; ++i) {
       const int idx = tid + i * 256;
       if (idx < G::NVW) *reinterpret_cast<uint4*>(buf + G::IN_BYTES + idx * 16) = qw[i];
+    }
+  };
+
+  // ---- stem-fused loader. The halo tile's NPIX pixels are taken in groups of 16 (SGW groups per wave); a group is ONE B operand
+  // of v_mfma_f32_16x16x32_f16: lane (n = lane % 16, kb = lane / 16) holds 8 of the 27 (+5 zero) taps x channels of the stem's 3x3
+  // stride-2 window around pixel n — kb < 3: window row kb, bytes 0..7 of its 9; kb = 3: byte 8 of the three rows — as fp16, which
+  // holds a u8 exactly. The / 255 sits in the weights (packed hi + lo fp16, stem_pack_kernel), so two MFMAs per 16 channels give
+  // the fp32-grade sum; lane (n, g = kb) ends with channels 4g..4g+3 of pixel n: bias, SiLU, zero outside the stem map (the conv's
+  // own zero padding), then the same split records the fp32 loader writes. Chunk 0 goes to the stage, chunk 1 waits in registers.
+  constexpr int SG = (NPIX + 15) / 16, SGW = (SG + 3) / 4;
+  uint2 s1h[STEM ? SGW : 1], s1l[STEM ? SGW : 1];
+  auto stem_fill = [&](unsigned char* buf) {
+    if constexpr (STEM) {
+      static_assert(!STEM || (KC == 16 && SPLIT && KS == 3 && STRIDE == 2), "stem-fused loader: split 3x3 stride 2, 16-channel chunks");
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+      const int n = lane & 15, kb = lane >> 4;
+      const int item = a.tiles[tile].x;
+      const LetterboxImg Lb = a.st_imgs[item];
+      const int4 nt = a.st_tab[item];
+      const int Hn = nt.y, Wn = nt.z;
+      const uint4* swp = reinterpret_cast<const uint4*>(a.st_w) + lane;
+      union FU { uint4 u; f16x8 h; };
+      FU afr[2][2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) afr[c][part].u = swp[(c * 2 + part) * 64];
+      const float4 sb[2] = {*reinterpret_cast<const float4*>(a.st_bias + 4 * kb), *reinterpret_cast<const float4*>(a.st_bias + 16 + 4 * kb)};
+      // B operands of all groups first (their loads in flight together), then the arithmetic
+      uint4 bq[SGW];
+      const f16x2 k1024 = {(_Float16)1024.f, (_Float16)1024.f};
+      auto to_half = [&](unsigned two_bytes_spread) {       // (b0 | b1 << 16) -> two fp16: 0x6400 | v is 1024 + v, exactly
+        union { unsigned u; f16x2 h; } t;
+        t.u = 0x64006400u | two_bytes_spread;
+        t.h = t.h - k1024;
+        return t.u;
+      };
+      auto geom = [&](int j, int& q, int& sy, int& sx) {
+        q = (wave * SGW + j) * 16 + n;
+        const int hy = q / HW, hx = q - hy * HW;
+        sy = iy0 + hy; sx = ix0 + hx;
+        return q < NPIX && (unsigned)sy < (unsigned)Hi && (unsigned)sx < (unsigned)Wi;
+      };
+      // item-uniform: the network image IS the source crop (no resize, no padding) — SAHI slices at their native size
+      const bool plain = __builtin_amdgcn_readfirstlane((int)(Lb.new_w == Lb.sw && Lb.new_h == Lb.sh && Lb.top == 0 && Lb.left == 0)) != 0;
+      if (plain) {
+        // lane (n, kb) reads the 9 bytes of window row min(kb, 2) as three aligned dwords through a range-checked resource (a dword
+        // wholly outside the frame reads zero); kb = 3 takes byte 8 of the three rows from its neighbours' registers
+        const auto rs_f = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<unsigned char*>(a.st_frame)), 0, a.st_bytes, 0x00020000);
+        const int r = kb < 3 ? kb : 2;
+        unsigned w0[SGW], w1[SGW], w2[SGW];
+#pragma unroll
+        for (int j = 0; j < SGW; ++j) {
+          int q, sy, sx;
+          const bool inmap = geom(j, q, sy, sx);
+          const int ny = 2 * sy - 1 + r;
+          const int A = ((Lb.y0 + ny) * a.st_W + Lb.x0 + 2 * sx - 1) * 3;
+          const unsigned base = (inmap && (unsigned)ny < (unsigned)Hn) ? (unsigned)(A & ~3) : OOB;
+          w0[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_f, base, 0, 0);
+          w1[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_f, base == OOB ? OOB : base + 4u, 0, 0);
+          w2[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_f, base == OOB ? OOB : base + 8u, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < SGW; ++j) {
+          int q, sy, sx;
+          const bool inmap = geom(j, q, sy, sx);
+          const int ny = 2 * sy - 1 + r;
+          const bool rowok = inmap && (unsigned)ny < (unsigned)Hn;
+          const unsigned al = (unsigned)(((Lb.y0 + ny) * a.st_W + Lb.x0 + 2 * sx - 1) * 3) & 3u;
+          unsigned d0 = __builtin_amdgcn_alignbyte(w1[j], w0[j], al), d1 = __builtin_amdgcn_alignbyte(w2[j], w1[j], al);
+          unsigned b8 = __builtin_amdgcn_alignbyte(0u, w2[j], al) & 0xFFu;
+          if (sx == 0) d0 &= 0xFF000000u;                    // window column -1: the stem's own zero padding
+          if (!rowok) { d0 = 0u; d1 = 0u; b8 = 0u; }
+          const unsigned t0 = (unsigned)__shfl((int)b8, n), t1 = (unsigned)__shfl((int)b8, n + 16), t2 = (unsigned)__shfl((int)b8, n + 32);
+          if (kb == 3) { d0 = t0 | (t1 << 8) | (t2 << 16); d1 = 0u; }
+          bq[j] = make_uint4(to_half(__builtin_amdgcn_perm(0u, d0, 0x0c010c00u)), to_half(__builtin_amdgcn_perm(0u, d0, 0x0c030c02u)),
+                             to_half(__builtin_amdgcn_perm(0u, d1, 0x0c010c00u)), to_half(__builtin_amdgcn_perm(0u, d1, 0x0c030c02u)));
+        }
+      } else {
+#pragma unroll 1
+        for (int j = 0; j < SGW; ++j) {
+          int q, sy, sx;
+          const bool inmap = geom(j, q, sy, sx);
+          int v[3][3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const int rr = kb < 3 ? kb : t, c = kb < 3 ? t : 2;
+            const int ny = 2 * sy - 1 + rr, nx = 2 * sx - 1 + c;
+            v[t][0] = v[t][1] = v[t][2] = 0;
+            if (inmap && (unsigned)ny < (unsigned)Hn && (unsigned)nx < (unsigned)Wn) letterbox_sample(a.st_frame, a.st_W, Lb, ny, nx, v[t]);
+          }
+          const bool row = kb < 3;
+          const unsigned e0 = row ? v[0][0] : v[0][2], e1 = row ? v[0][1] : v[1][2], e2 = row ? v[0][2] : v[2][2];
+          const unsigned e3 = row ? v[1][0] : 0, e4 = row ? v[1][1] : 0, e5 = row ? v[1][2] : 0, e6 = row ? v[2][0] : 0, e7 = row ? v[2][1] : 0;
+          const uint4 bj = make_uint4(to_half(e0 | (e1 << 16)), to_half(e2 | (e3 << 16)), to_half(e4 | (e5 << 16)), to_half(e6 | (e7 << 16)));
+          // static register indexing only: bq[] lives in registers
+#pragma unroll
+          for (int jj = 0; jj < SGW; ++jj) if (jj == j) bq[jj] = bj;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < SGW; ++j) {
+        int q, sy, sx;
+        const bool inmap = geom(j, q, sy, sx);
+        FU bfr;
+        bfr.u = bq[j];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+          d = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[c][0].h, bfr.h, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[c][1].h, bfr.h, d, 0, 0, 0);
+          float o0 = apply_act(fmaf(d[0], a.st_scale, sb[c].x), ACT_SILU), o1 = apply_act(fmaf(d[1], a.st_scale, sb[c].y), ACT_SILU);
+          float o2 = apply_act(fmaf(d[2], a.st_scale, sb[c].z), ACT_SILU), o3 = apply_act(fmaf(d[3], a.st_scale, sb[c].w), ACT_SILU);
+          if (!inmap) o0 = o1 = o2 = o3 = 0.f;
+          uint2 hi, lo;
+          split_pair(o0, o1, tscale, hi.x, lo.x);
+          split_pair(o2, o3, tscale, hi.y, lo.y);
+          if (c == 0) {
+            if (q < NPIX) {
+              unsigned char* rec = buf + q * PS + kb * 8;
+              *reinterpret_cast<uint2*>(rec) = hi;
+              *reinterpret_cast<uint2*>(rec + KC * 2) = lo;
+            }
+          } else {
+            s1h[j] = hi; s1l[j] = lo;
+          }
+        }
+      }
+    }
+  };
+  auto stem_flush = [&](unsigned char* buf) {
+    if constexpr (STEM) {
+      const int n = lane & 15, kb = lane >> 4;
+#pragma unroll
+      for (int j = 0; j < SGW; ++j) {
+        const int q = (wave * SGW + j) * 16 + n;
+        if (q < NPIX) {
+          unsigned char* rec = buf + q * PS + kb * 8;
+          *reinterpret_cast<uint2*>(rec) = s1h[j];
+          *reinterpret_cast<uint2*>(rec + KC * 2) = s1l[j];
+        }
+      }
     }
   };
 
@@ -382,6 +528,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (d * KC < a.cin && (d == 0 || !(a.dbg & 4))) fetch(d * KC, ri[d], rw[d]);
+  stem_fill(smem);
   stash(smem, ri[0], rw[0]);
   __syncthreads();
   int cur = 0;
@@ -396,10 +543,10 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
         // chunk c0 + KC was requested D - 1 iterations ago: move it into the other stage (last read one barrier ago)
         if constexpr (G::STAGES == 1) {
           __syncthreads();                                             // everyone is done reading the only stage
-          if (c0 + KC < a.cin && !(a.dbg & 8)) stash(smem, ri[(d + 1) % D], rw[(d + 1) % D]);
+          if (c0 + KC < a.cin && !(a.dbg & 8)) { stem_flush(smem); stash(smem, ri[(d + 1) % D], rw[(d + 1) % D]); }
           __syncthreads();
         } else {
-          if (c0 + KC < a.cin && !(a.dbg & 8)) stash(smem + (cur ^ 1) * G::BUF, ri[(d + 1) % D], rw[(d + 1) % D]);
+          if (c0 + KC < a.cin && !(a.dbg & 8)) { stem_flush(smem + (cur ^ 1) * G::BUF); stash(smem + (cur ^ 1) * G::BUF, ri[(d + 1) % D], rw[(d + 1) % D]); }
           __syncthreads();
           cur ^= 1;
         }
@@ -737,6 +884,65 @@ static const void* zero_block() {
   return it->second.p;
 }
 
+// ---- stem fused into the first MFMA conv (conv_mfma_kernel<X3, 3, 2, 4, 1, 1, 2, 16, true>) ------------------------------------
+namespace {
+using StemG = Geo<X3, 3, 2, 4, 1, 1, 2, 16>;
+constexpr float kStemWScale = 4096.f;      // the packed stem weights are w / 255 * 2^12: fp16 normal range for every weight that matters
+
+// fp32 stem weights [tap][net channel][cout] -> A fragments of v_mfma_f32_16x16x32_f16 in the loader's k order (see stem_fill):
+// out[((chunk * 2 + part) * 64 + lane) * 8 + i], part 0 = hi, 1 = lo; lane = (channel % 16) + 16 * kb
+__global__ void stem_pack_kernel(const float* __restrict__ w, int cout, int flip, _Float16* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * 64 * 8) return;
+  const int i = idx & 7, lane = (idx >> 3) & 63, chunk = idx >> 9;
+  const int ch = chunk * 16 + (lane & 15), kb = lane >> 4;
+  int r = -1, col = 0, sc = 0;                      // window row / column / source channel of k slot (kb, i); r < 0: zero slot
+  if (kb < 3) { r = kb; col = i / 3; sc = i % 3; }
+  else if (i < 3) { r = i; col = 2; sc = 2; }
+  float v = 0.f;
+  if (r >= 0 && ch < cout) v = w[((r * 3 + col) * 3 + (flip ? 2 - sc : sc)) * cout + ch] / 255.0f * kStemWScale;
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  out[((chunk * 2 + 0) * 64 + lane) * 8 + i] = hi;
+  out[((chunk * 2 + 1) * 64 + lane) * 8 + i] = lo;
+}
+}  // namespace
+
+bool stem_conv_eligible(const ConvOp& stem, const ConvOp& conv) {
+  const PackedConv& ps = *stem.pc;
+  const PackedConv& pc = *conv.pc;
+  static const bool off = [] { const char* e = getenv("FFP_NO_STEM_FUSE"); return e && e[0] == '1'; }();
+  return !off && conv_direct_eligible(stem) && ps.dt == F32 && stem.stride == 2 && stem.act == ACT_SILU && ps.cout == 32 && ps.w_direct.p != nullptr &&
+         pc.split && pc.dt == F32 && pc.k == 3 && conv.stride == 2 && pc.cin == 32 && pc.cout_pad == 64 && !conv.up && !conv.has_res1 && !conv.has_res2 &&
+         !conv.has_up2 && conv.in.lvl == stem.out.lvl && conv.in.amax != nullptr && !conv.out.lvl->capacity();
+}
+
+void stem_conv_pack(const ConvOp& stem, int flip, DevBuf& out, hipStream_t st) {
+  out.alloc(2 * 2 * 64 * 16);
+  hipLaunchKernelGGL(stem_pack_kernel, dim3(4), dim3(256), 0, st, stem.pc->w_direct.as<float>(), stem.pc->cout, flip, out.as<_Float16>());
+  FFP_HIP(hipGetLastError());
+}
+
+void launch_stem_conv(const uint8_t* d_frame, int H, int W, const DevBuf& d_imgs, const DevBuf& stem_w, const ConvOp& stem, const ConvOp& conv, hipStream_t st) {
+  FFP_CHECK(stem_conv_eligible(stem, conv), FFP_ERR_ARG, "conv %s: not eligible for the stem-fused loader", conv.pc->name.c_str());
+  ConvArgs a = make_conv_args(conv);
+  a.in = nullptr;                                  // never read
+  a.st_frame = d_frame; a.st_W = W;
+  FFP_CHECK((long long)H * W * 3 < (1ll << 31), FFP_ERR_ARG, "stem-fused conv: frame of %dx%d exceeds the 2 GiB the loader addresses", W, H);
+  a.st_bytes = H * W * 3;
+  a.st_imgs = d_imgs.as<LetterboxImg>();
+  a.st_tab = stem.in.lvl->d_tab.as<int4>();
+  a.st_w = stem_w.p;
+  a.st_bias = stem.pc->bias.as<float>();
+  a.st_scale = 1.0f / kStemWScale;
+  int n_tiles = 0;
+  a.tiles = conv.out.lvl->tile_table(StemG::TH, &n_tiles, &a.n_tiles_dev, st);
+  a.n_nblk = 1;
+  if (n_tiles == 0) return;
+  hipLaunchKernelGGL((conv_mfma_kernel<X3, 3, 2, 4, 1, 1, 2, 16, true>), dim3(n_tiles), dim3(256), StemG::LDS, st, a);
+  FFP_HIP(hipGetLastError());
+}
+
 void conv_kernels_init() {
   (void)zero_block();
   static bool done = false;
@@ -747,6 +953,7 @@ void conv_kernels_init() {
   Family<float, 1, 1>::init(); Family<float, 3, 1>::init(); Family<float, 3, 2>::init();
   Family<_Float16, 1, 1>::init(); Family<_Float16, 3, 1>::init(); Family<_Float16, 3, 2>::init();
   Family<X3, 1, 1>::init(); Family<X3, 3, 1>::init(); Family<X3, 3, 2>::init();
+  FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<X3, 3, 2, 4, 1, 1, 2, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, StemG::LDS));
   done = true;
 }
 

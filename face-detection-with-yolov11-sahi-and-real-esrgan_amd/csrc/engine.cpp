@@ -70,11 +70,22 @@ double Plan::actual_conv_flops() const {
 }
 
 TView Plan::alloc(Level* l, int C, DType dt) {
-  const size_t nb = (size_t)l->total_px * C * dsize(dt) + 256;   // slack: vector loads of the last record stay in bounds
+  TView v = alloc_virtual(l, C, dt);
+  materialize(v);
+  return v;
+}
+
+void Plan::materialize(TView& v) {
+  if (v.ptr) return;
+  const size_t nb = (size_t)v.lvl->total_px * v.cs * dsize(v.dt) + 256;   // slack: vector loads of the last record stay in bounds
   bufs.emplace_back(nb);
   bytes += nb;
+  v.ptr = bufs.back().p;
+}
+
+TView Plan::alloc_virtual(Level* l, int C, DType dt) {
   TView v;
-  v.ptr = bufs.back().p; v.dt = dt; v.cs = C; v.coff = 0; v.C = C; v.lvl = l;
+  v.ptr = nullptr; v.dt = dt; v.cs = C; v.coff = 0; v.C = C; v.lvl = l;
   if (!amax_slots.p) amax_slots.alloc(sizeof(unsigned) * AMAX_CAP);
   FFP_CHECK((int)amax_init.size() < AMAX_CAP, FFP_ERR_STATE, "plan: more than %d buffers", AMAX_CAP);
   v.amax = amax_slots.as<unsigned>() + amax_init.size();
@@ -97,6 +108,10 @@ void Plan::add_amax_reset(hipStream_t st) {
   unsigned* slots = amax_slots.as<unsigned>();
   const unsigned* init = amax_init_dev.as<unsigned>();
   const int n = (int)amax_init.size();
+  if (reset_outside) {
+    reset_fn = [slots, init, n](hipStream_t q) { launch_amax_init(slots, init, n, q); };
+    return;
+  }
   Step s;
   s.run = [slots, init, n](hipStream_t q) { launch_amax_init(slots, init, n, q); };
   steps.insert(steps.begin(), std::move(s));

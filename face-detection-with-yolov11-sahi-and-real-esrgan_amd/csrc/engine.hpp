@@ -49,6 +49,10 @@ struct Plan {
   std::vector<unsigned> amax_init;
   void set_amax_bound(const TView& v, float bound);      // a bound known without looking at data (image inputs, stem output)
   void add_amax_reset(hipStream_t st);                   // uploads the initial values and appends the reset step
+  // reset_outside: the owner launches `reset_fn` itself, ahead of work it runs before execute() (the detector's stem-fused first
+  // conv raises a max-|value| slot and needs the frame pointer, so it cannot be one of the captured steps)
+  bool reset_outside = false;
+  std::function<void(hipStream_t)> reset_fn;
   // The launch sequence of a plan is fixed (every pointer is plan-owned), so after one eager run it is captured into a
   // hipGraph and replayed: ~110 (detector) / ~355 (SR) launches per frame become one graph launch.
   hipGraph_t graph = nullptr;
@@ -63,6 +67,8 @@ struct Plan {
   double actual_conv_flops() const;     // algorithmic FLOPs of the batch the levels currently describe (capacity-mode plans)
   int graph_state() const { return gexec ? 1 : graph_ok ? 0 : -1; }    // 1 replaying a captured graph, 0 not captured yet, -1 capture failed: eager
   TView alloc(Level* l, int C, DType dt);
+  TView alloc_virtual(Level* l, int C, DType dt);        // a view with a max-|value| slot but no storage yet: a tensor that may be fused away
+  void materialize(TView& v);                            // ... and its storage, once some kernel turns out to need it
   void add_conv(const ConvOp& op);
   void add(std::function<void(hipStream_t)> f) { Step s; s.run = std::move(f); steps.push_back(std::move(s)); }
   void execute(hipStream_t st, ConvProfile* prof);

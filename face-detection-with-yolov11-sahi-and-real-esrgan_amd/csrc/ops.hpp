@@ -36,6 +36,12 @@ void conv_kernels_init();   // raise dynamic-LDS limits once per process
 // times the valid workgroup shapes of a generic-kernel conv on its own buffers; returns the fastest shape id, or -1 when
 // the op has a single candidate / goes to a specialised kernel (direct stem, row-reuse)
 int conv_tune(const ConvOp& op, hipStream_t st);
+// The image-input conv computed inside the loader of the conv that consumes it (fp32-split plans, YOLO11s: model.0 -> model.1): the
+// stem's output (1 GB per 2-frame group of 4K slices) is neither written nor read back. stem_conv_pack() lays the stem weights out
+// as MFMA fragments for one channel order; launch_stem_conv() needs the frame, so it runs outside the plan's captured steps.
+bool stem_conv_eligible(const ConvOp& stem, const ConvOp& conv);       // env FFP_NO_STEM_FUSE=1: never
+void stem_conv_pack(const ConvOp& stem, int flip, DevBuf& out, hipStream_t st);
+void launch_stem_conv(const uint8_t* d_frame, int H, int W, const DevBuf& d_imgs, const DevBuf& stem_w, const ConvOp& stem, const ConvOp& conv, hipStream_t st);
 
 // Depthwise 3x3, stride 1 (YOLO11 cls-tower DWConv and the PSA positional conv), fp32 math.
 // Input channel c is read from  in.coff + (c / grp) * grp_stride + grp_off + c % grp  (grp = C: identity) so that the

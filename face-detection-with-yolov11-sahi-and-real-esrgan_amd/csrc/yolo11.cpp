@@ -140,27 +140,45 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
   const TView x13 = cat18.slice(c256, c512), x10 = cat21.slice(c512, c1024);
 
   // ---- backbone --------------------------------------------------------------------------------------------------------
-  TView x0 = P.alloc(P.L[1], c64, T);
+  TView x0 = P.alloc_virtual(P.L[1], c64, T);      // stored only if a kernel reads it (not when model.1's loader computes it)
+  TView x1 = P.alloc(P.L[2], c128, T);
   {   // stem: fused with the letterbox when the direct image-input kernel applies (always, for 3-channel frames)
-    ConvOp o;
+    ConvOp o, m1;
     o.pc = conv("model.0.conv"); o.in = P.input; o.out = x0; o.stride = 2; o.act = ACT_SILU;
     FFP_CHECK(o.pc->cin == cin0 && o.pc->cout == c64, FFP_ERR_WEIGHTS, "model.0.conv: weights are %d->%d, graph expects %d->%d", o.pc->cin,
               o.pc->cout, cin0, c64);
-    if (conv_direct_eligible(o) && !getenv("FFP_NO_FUSED_STEM")) {
-      o.flops = conv_flops_of(*o.pc, x0.lvl->total_px);
-      P.stem = o; P.fused_stem = true;
-      P.conv_flops += o.flops; P.conv_launches += 1;
-    } else {
-      P.input = P.alloc(P.L[0], cin0, T);
-      P.set_amax_bound(P.input, 1.0f);                 // pixels / 255
-      cv("model.0.conv", P.input, x0, 2, ACT_SILU);   // reads the 4/8-channel padded image (weights zero padded at pack)
-    }
-    // the image-input conv runs on the direct (VALU) kernel: its output bound is known from the weights alone (inputs in [0, 1],
-    // |SiLU(v)| <= max(|v|, 0.279)), so the first MFMA conv finds its input's exponent without a pass over the data
+    m1.pc = conv("model.1.conv"); m1.in = x0; m1.out = x1; m1.stride = 2; m1.act = ACT_SILU;
+    FFP_CHECK(m1.pc->cin == x0.C && m1.pc->cout == x1.C, FFP_ERR_WEIGHTS, "model.1.conv: weights are %d->%d, graph expects %d->%d", m1.pc->cin,
+              m1.pc->cout, x0.C, x1.C);
+    const bool direct = conv_direct_eligible(o) && !getenv("FFP_NO_FUSED_STEM");
+    // the image-input conv's output bound is known from the weights alone (inputs in [0, 1], |SiLU(v)| <= max(|v|, 0.279)), so the
+    // first MFMA conv finds its input's exponent without a pass over the data
     P.set_amax_bound(x0, std::max(o.pc->out_bound, 0.3f));
+    if (direct && stem_conv_eligible(o, m1)) {
+      // fp32-split YOLO11s: model.0 runs inside model.1's loader on the matrix cores; x0 is never stored
+      o.flops = conv_flops_of(*o.pc, x0.lvl->total_px);
+      m1.flops = conv_flops_of(*m1.pc, x1.lvl->total_px);
+      P.stem = o; P.fused_stem = true;
+      P.stemconv = m1; P.fused_stem_conv = true;
+      P.stemconv_variant = "f32x3_k3s2_stem_fused";
+      P.conv_flops += o.flops + m1.flops; P.conv_launches += 1;
+      P.reset_outside = true;                          // the fused launch raises x1's max-|value| slot before execute()
+      for (int f = 0; f < 2; ++f) stem_conv_pack(o, f, P.stem_w[f], st_);
+    } else {
+      P.materialize(x0);
+      o.out = x0; m1.in = x0;
+      if (direct) {
+        o.flops = conv_flops_of(*o.pc, x0.lvl->total_px);
+        P.stem = o; P.fused_stem = true;
+        P.conv_flops += o.flops; P.conv_launches += 1;
+      } else {
+        P.input = P.alloc(P.L[0], cin0, T);
+        P.set_amax_bound(P.input, 1.0f);                 // pixels / 255
+        cv("model.0.conv", P.input, x0, 2, ACT_SILU);   // reads the 4/8-channel padded image (weights zero padded at pack)
+      }
+      P.add_conv(m1);
+    }
   }
-  TView x1 = P.alloc(P.L[2], c128, T);
-  cv("model.1.conv", x0, x1, 2, ACT_SILU);
   TView x2 = P.alloc(P.L[2], c256, T);
   c3k2("model.2", x1, x2, c256, false, 0.25);
   TView x3 = P.alloc(P.L[3], c256, T);
@@ -339,10 +357,18 @@ DetPlan* DetEngine::prepare(const uint8_t* d_frame, int H, int W, int chan_order
   FFP_HIP(hipStreamSynchronize(st_));   // lb/di are stack vectors
   FFP_HIP(hipEventRecord(ev_[0], st_));
   const int flip = chan_order == FFP_CHAN_AS_BGR ? 1 : 0;
-  if (P->fused_stem) launch_stem_from_frame(d_frame, H, W, flip, P->d_lb, P->stem, st_);
-  else launch_letterbox(d_frame, H, W, flip, P->d_lb, P->input, st_);
-  FFP_HIP(hipEventRecord(ev_[1], st_));
   if (prof.enabled) prof.begin();
+  if (P->fused_stem_conv) {
+    P->reset_fn(st_);
+    const int slot = prof.enabled ? prof.open(st_) : -1;
+    launch_stem_conv(d_frame, H, W, P->d_lb, P->stem_w[flip], P->stem, P->stemconv, st_);
+    if (slot >= 0) prof.close(slot, st_, P->stemconv_variant, P->stem.flops + P->stemconv.flops, "model.0.conv+model.1.conv");
+  } else if (P->fused_stem) {
+    launch_stem_from_frame(d_frame, H, W, flip, P->d_lb, P->stem, st_);
+  } else {
+    launch_letterbox(d_frame, H, W, flip, P->d_lb, P->input, st_);
+  }
+  FFP_HIP(hipEventRecord(ev_[1], st_));
   P->execute(st_, &prof);
   FFP_HIP(hipEventRecord(ev_[2], st_));
   last_conv_flops = P->conv_flops;

@@ -13,6 +13,11 @@ struct DetPlan : Plan {
   int total_anchors = 0;
   ConvOp stem;              // model.0 when it is fused with the letterbox (runs ahead of the captured launch sequence)
   bool fused_stem = false;
+  // fp32-split plans of YOLO11s: model.0 is computed inside model.1's loader (launch_stem_conv) and its output never stored
+  ConvOp stemconv;
+  bool fused_stem_conv = false;
+  std::string stemconv_variant;
+  DevBuf stem_w[2];         // the stem's MFMA fragments per channel order (RGB, BGR frames)
 };
 
 struct TileGeom {       // host-side geometry of one crop

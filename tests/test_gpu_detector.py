@@ -129,3 +129,33 @@ def test_f32x3_detector_with_bn_fold_like_channel_scales(gpu_lib, K):
         np.testing.assert_allclose(outs["f32x3"][i][4], r[4], atol=2e-4, rtol=0)
         np.testing.assert_allclose(outs["f32x3"][i][:4], r[:4], atol=2e-2, rtol=0)
         assert e3[:5].max() <= max(3 * e1[:5].max(), 5e-3), (K, e3[:5].max(), e1[:5].max())
+
+
+@pytest.mark.parametrize("order", [0, 1], ids=["as_bgr", "as_rgb"])
+def test_stem_fused_into_first_conv_runs_and_matches_oracle(gpu_lib, order):
+    """YOLO11s in the default arithmetic computes model.0 inside model.1's loader (conv_mfma_kernel<..., STEM>, no stored stem
+    output). The profile must name the fused launch (so this cannot pass on the two-kernel path), and the raw head outputs must
+    meet the usual bars for a native-size slice (the dword fast path, image border on every side), an interior slice, a
+    down-scaled full frame (resize + letterbox padding), an up-scaled crop and an odd-offset slice, in both channel orders."""
+    from ffp_amd import synth
+    from oracle import ultra_post
+    from oracle.yolo11_ref import Yolo11PoseRef
+    W = synth.yolo11_pose_weights("s")
+    ref = Yolo11PoseRef(W, "s")
+    det = gpu_lib.Detector(W, arch="s", precision=gpu_lib.PREC_F32X3)
+    frame = synth.synthetic_frame(300, 420, seed=33)
+    tiles = [(0, 0, 256, 256), (164, 44, 420, 300), (0, 0, 420, 300), (30, 40, 190, 140), (5, 7, 261, 263)]
+    det.set_profile(True)
+    outs = det.forward_raw(frame, tiles, 256, chan_order=order)
+    names = [e["name"] for e in det.profile_detail()]
+    det.set_profile(False)
+    assert any("stem_fused" in n and "model.1.conv" in n for n in names), names[:4]
+    assert not any(n.endswith(" model.1.conv") for n in names)
+    for t, o in zip(tiles, outs):
+        crop = frame[t[1]:t[3], t[0]:t[2]]
+        if order == gpu_lib.CHAN_AS_RGB:
+            crop = crop[..., ::-1]              # the oracle's preprocess takes BGR like cv2.imread
+        r = ref.forward(ultra_post.preprocess(np.ascontiguousarray(crop), 256))[0].numpy()
+        np.testing.assert_allclose(o[4], r[4], atol=2e-4, rtol=0)
+        np.testing.assert_allclose(o[:4], r[:4], atol=2e-2, rtol=0)
+        np.testing.assert_allclose(o[5:], r[5:], atol=2e-2, rtol=1e-4)
