@@ -929,7 +929,7 @@ void launch_stem_conv(const uint8_t* d_frame, int H, int W, const DevBuf& d_imgs
   a.in = nullptr;                                  // never read
   a.st_frame = d_frame; a.st_W = W;
   FFP_CHECK((long long)H * W * 3 < (1ll << 31), FFP_ERR_ARG, "stem-fused conv: frame of %dx%d exceeds the 2 GiB the loader addresses", W, H);
-  a.st_bytes = H * W * 3;
+  a.st_bytes = (H * W * 3 + 3) & ~3;              // whole dwords: the last pixel's dword may end up to 3 bytes past the frame (inside the allocation granule)
   a.st_imgs = d_imgs.as<LetterboxImg>();
   a.st_tab = stem.in.lvl->d_tab.as<int4>();
   a.st_w = stem_w.p;

@@ -143,8 +143,8 @@ def test_stem_fused_into_first_conv_runs_and_matches_oracle(gpu_lib, order):
     W = synth.yolo11_pose_weights("s")
     ref = Yolo11PoseRef(W, "s")
     det = gpu_lib.Detector(W, arch="s", precision=gpu_lib.PREC_F32X3)
-    frame = synth.synthetic_frame(300, 420, seed=33)
-    tiles = [(0, 0, 256, 256), (164, 44, 420, 300), (0, 0, 420, 300), (30, 40, 190, 140), (5, 7, 261, 263)]
+    frame = synth.synthetic_frame(301, 421, seed=33)              # 301 x 421 x 3 bytes is not a whole number of dwords
+    tiles = [(0, 0, 256, 256), (165, 45, 421, 301), (0, 0, 421, 301), (30, 40, 190, 140), (5, 7, 261, 263)]
     det.set_profile(True)
     outs = det.forward_raw(frame, tiles, 256, chan_order=order)
     names = [e["name"] for e in det.profile_detail()]

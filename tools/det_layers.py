@@ -21,6 +21,13 @@ tot_ms = tot_b = 0
 rows = []
 for x in det:
     variant, name = x["name"].split(" ", 1)
+    if "+" in name:         # model.0 computed in model.1's loader: reads the u8 network image, writes model.1's output; nothing in between
+        w0, w1 = Wd["model.0.conv.weight"], Wd["model.1.conv.weight"]
+        px1 = x["flops"] / (2.0 * (w0.shape[1] * 9 * w0.shape[0] * 4 + w1.shape[1] * 9 * w1.shape[0]))
+        by = px1 * 16 * 3 + px1 * w1.shape[0] * 4
+        rows.append((x["ms"], name, variant, 3, w1.shape[0], 3, by))
+        tot_ms += x["ms"]; tot_b += by
+        continue
     w = Wd[name + ".weight"]
     cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
     px_out = x["flops"] / (2.0 * cin * k * k * cout)

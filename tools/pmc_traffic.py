@@ -24,7 +24,9 @@ def variant(sym: str):
     m = re.search(r"conv_rows_kernel<(\d+), *(\d+)>", sym) or re.search(r"conv_rows_kernelILi(\d+)ELi(\d+)E", sym)
     if m:
         return "f16_k3s1_rows"
-    m = re.search(r"conv_mfma_kernel<([^,]+), *(\d+), *(\d+), *(\d+), *(\d+), *(\d+), *(\d+), *(\d+)>", sym)
+    if re.search(r"conv_mfma_kernel<[^>]*, *true>", sym) or re.search(r"conv_mfma_kernelI.*Lb1EEE", sym):
+        return "f32x3_k3s2_stem_fused"                     # model.0 computed in model.1's loader
+    m = re.search(r"conv_mfma_kernel<([^,]+), *(\d+), *(\d+), *(\d+), *(\d+), *(\d+), *(\d+), *(\d+)(?:, *false)?>", sym)
     if m:
         t, ks, s, wm, wn, mi, niw, kc = m.group(1), *map(int, m.groups()[1:])
     else:
