@@ -1,5 +1,5 @@
 """Per-layer time, algorithmic HBM bytes and achieved GB/s of the detector's convolutions for a 2-frame group (122 items).
-Usage on the GPU box: python tools/det_layers.py [--f32]"""
+Usage on the GPU box: python tools/det_layers.py [--f32] [--all]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,5 +37,7 @@ for x in det:
     rows.append((x["ms"], name, variant, cin, cout, k, by))
     tot_ms += x["ms"]; tot_b += by
 print(f"total conv {tot_ms:.3f} ms for {NF} frames, algorithmic bytes {tot_b/1e9:.2f} GB -> {tot_b/tot_ms/1e9:.2f} TB/s average; graph-mode stage ms:", pipe.det.last_ms())
-for ms, name, variant, cin, cout, k, by in sorted(rows, reverse=True)[:40]:
-    print(f"{name:34s} {variant:22s} {cin:4d}->{cout:4d} k{k} {ms*1e3:8.1f} us {by/1e6:8.1f} MB {by/ms/1e9:6.2f} TB/s")
+flops = {x["name"].split(" ", 1)[1]: x["flops"] for x in det}
+split = 1 if "--f32" in sys.argv else 3              # MFMA products per algorithmic MAC in the split arithmetic
+for ms, name, variant, cin, cout, k, by in sorted(rows, reverse=True)[:(200 if "--all" in sys.argv else 40)]:
+    print(f"{name:34s} {variant:22s} {cin:4d}->{cout:4d} k{k} {ms*1e3:8.1f} us {by/1e6:8.1f} MB {by/ms/1e9:6.2f} TB/s  {flops[name]*split/ms/2.5e12*100:5.1f} % of 2.5 PF")
