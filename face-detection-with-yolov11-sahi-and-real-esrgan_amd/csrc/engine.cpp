@@ -127,6 +127,7 @@ void Plan::add_conv(const ConvOp& op) {
   s.flops = o.flops;
   s.conv = std::make_shared<ConvOp>(o);
   std::shared_ptr<ConvOp> cp = s.conv;
+  s.lane = cur_lane;
   s.run = [cp](hipStream_t st) { launch_conv(*cp, st); };
   conv_flops += o.flops;
   conv_launches += 1;
@@ -156,6 +157,48 @@ CaptureExclusive::~CaptureExclusive() {
 Plan::~Plan() {
   if (gexec) (void)hipGraphExecDestroy(gexec);
   if (graph) (void)hipGraphDestroy(graph);
+  for (Step& s : steps) if (s.ev) (void)hipEventDestroy(s.ev);
+  for (hipStream_t q : lane_streams) (void)hipStreamDestroy(q);
+}
+
+bool Plan::lanes_enabled() const {
+  static const bool on = [] { const char* e = getenv("FFP_LANES"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+void Plan::fork(int lane) {
+  if (!lanes_enabled() || lane <= 0) return;
+  while ((int)lane_streams.size() < lane) {
+    hipStream_t q;
+    FFP_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    lane_streams.push_back(q);
+  }
+  Step s;
+  s.kind = 1; s.lane = lane;
+  FFP_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+  steps.push_back(std::move(s));
+}
+
+void Plan::join(int lane) {
+  if (!lanes_enabled() || lane <= 0) return;
+  Step s;
+  s.kind = 2; s.lane = lane;
+  FFP_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+  steps.push_back(std::move(s));
+}
+
+// use_lanes = false: every step on `st` in issue order (a valid serialisation: forks / joins only relax the order)
+void Plan::run_steps(hipStream_t st, bool use_lanes) {
+  for (Step& s : steps) {
+    hipStream_t q = (use_lanes && s.lane > 0) ? lane_streams[s.lane - 1] : st;
+    if (s.kind == 1) {
+      if (use_lanes) { FFP_HIP(hipEventRecord(s.ev, st)); FFP_HIP(hipStreamWaitEvent(q, s.ev, 0)); }
+    } else if (s.kind == 2) {
+      if (use_lanes) { FFP_HIP(hipEventRecord(s.ev, q)); FFP_HIP(hipStreamWaitEvent(st, s.ev, 0)); }
+    } else {
+      s.run(q);
+    }
+  }
 }
 
 static bool graphs_enabled() {
@@ -182,6 +225,7 @@ void Plan::execute(hipStream_t st, ConvProfile* prof) {
   const bool p = prof && prof->enabled;
   if (p) {                                   // per-launch events: always eager
     for (Step& s : steps) {
+      if (s.kind != 0) continue;
       if (s.is_conv) {
         const int slot = prof->open(st);
         s.run(st);
@@ -199,7 +243,7 @@ void Plan::execute(hipStream_t st, ConvProfile* prof) {
       if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         bool ok = true;
         try {
-          for (Step& s : steps) s.run(st);
+          run_steps(st, true);
         } catch (...) {
           ok = false;
         }
@@ -231,7 +275,7 @@ void Plan::execute(hipStream_t st, ConvProfile* prof) {
       return;
     }
   }
-  for (Step& s : steps) s.run(st);
+  run_steps(st, runs > 0);      // the first run builds the lazily created tables: one stream
   ++runs;
 }
 

@@ -34,6 +34,11 @@ struct Step {
   std::shared_ptr<ConvOp> conv;      // is_conv: the descriptor `run` launches (its workgroup shape can be tuned after the plan is laid out)
   std::string variant, name;
   double flops = 0;
+  // lanes: steps of different lanes have no data dependency between a fork and the matching join and may overlap on the device
+  // (independent branches of the captured graph). kind 1 = fork: `lane` starts after everything lane 0 has issued so far;
+  // kind 2 = join: lane 0 continues after everything `lane` has issued.
+  int lane = 0, kind = 0;
+  hipEvent_t ev = nullptr;
 };
 
 struct Plan {
@@ -70,7 +75,14 @@ struct Plan {
   TView alloc_virtual(Level* l, int C, DType dt);        // a view with a max-|value| slot but no storage yet: a tensor that may be fused away
   void materialize(TView& v);                            // ... and its storage, once some kernel turns out to need it
   void add_conv(const ConvOp& op);
-  void add(std::function<void(hipStream_t)> f) { Step s; s.run = std::move(f); steps.push_back(std::move(s)); }
+  void add(std::function<void(hipStream_t)> f) { Step s; s.run = std::move(f); s.lane = cur_lane; steps.push_back(std::move(s)); }
+  // side lanes (FFP_LANES=0: everything stays on lane 0). New steps go to `cur_lane`.
+  int cur_lane = 0;
+  std::vector<hipStream_t> lane_streams;                 // lane k > 0 -> lane_streams[k - 1]
+  bool lanes_enabled() const;
+  void fork(int lane);                                   // no-op when lanes are disabled (the steps then run in issue order on lane 0)
+  void join(int lane);
+  void run_steps(hipStream_t st, bool use_lanes);
   void execute(hipStream_t st, ConvProfile* prof);
   // time every valid workgroup shape of every dense conv on the plan's own buffers and keep the fastest (all shapes give
   // bit-identical results: the accumulation order over k does not depend on the shape). FFP_NO_TUNE=1 keeps the heuristic.

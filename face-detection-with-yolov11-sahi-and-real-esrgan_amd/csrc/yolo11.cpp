@@ -237,17 +237,6 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
     const TView up = cat15.slice(0, c512);
     P.add([x13, up](hipStream_t s) { launch_upsample2x(x13, up, s); launch_amax_max(up.amax, x13.amax, s); });
   }
-  TView x16 = P.alloc(P.L[3], c256, T);
-  c3k2("model.16", cat15, x16, c256, false, 0.5, fold15 ? &x13 : nullptr);
-  cv("model.17.conv", x16, cat18.slice(0, c256), 2, ACT_SILU);
-  TView x19 = P.alloc(P.L[4], c512, T);
-  c3k2("model.19", cat18, x19, c512, false, 0.5);
-  cv("model.20.conv", x19, cat21.slice(0, c512), 2, ACT_SILU);
-  TView x22 = P.alloc(P.L[5], c1024, T);
-  c3k2("model.22", cat21, x22, c1024, true, 0.5);
-
-  // ---- Pose head: per level one fp32 record [64 DFL | nc | 3*nkpt] per pixel ---------------------------------------------
-  const TView feats[3] = {x16, x19, x22};
   const int chs[3] = {c256, c512, c1024};
   const int nk = 3 * nkpt_;
   const int no = 64 + nc_ + nk;
@@ -255,17 +244,22 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
   const int c2 = std::max(std::max(16, chs[0] / 4), 64);
   const int c3 = std::max(chs[0], std::min(nc_, 100));
   const int c4 = std::max(chs[0] / 4, nk);
-  for (int l = 0; l < 3; ++l) {
+  // One head level = three independent towers (box, class, keypoints) over one feature map. Each tower is a lane of its own,
+  // forked as soon as the map exists: level 0 (the large one, 1.2 of the head's 2.2 ms per 2-frame group) overlaps the rest of the
+  // neck, whose stride-16/32 launches (and the towers of levels 1 and 2) leave most of the chip idle on their own.
+  auto head_level = [&](int l, const TView& x) {
     Level* lv = P.L[3 + l];
     P.head[l] = P.alloc(lv, head_cs, F32);
     const std::string p = "model.23";
     const std::string ls = std::to_string(l);
-    const TView& x = feats[l];
     TView t1 = P.alloc(lv, c2, T), t2 = P.alloc(lv, c2, T);
+    for (int k = 1; k <= 3; ++k) P.fork(3 * l + k);
+    P.cur_lane = P.lanes_enabled() ? 3 * l + 1 : 0;
     cv(p + ".cv2." + ls + ".0.conv", x, t1, 1, ACT_SILU);
     cv(p + ".cv2." + ls + ".1.conv", t1, t2, 1, ACT_SILU);
     cv(p + ".cv2." + ls + ".2", t2, P.head[l].slice(0, 64), 1, ACT_NONE);
     TView d1 = P.alloc(lv, chs[l], T), e1 = P.alloc(lv, c3, T), d2 = P.alloc(lv, c3, T), e2 = P.alloc(lv, c3, T);
+    P.cur_lane = P.lanes_enabled() ? 3 * l + 2 : 0;
     dw(p + ".cv3." + ls + ".0.0.conv", x, d1, ACT_SILU);
     cv(p + ".cv3." + ls + ".0.1.conv", d1, e1, 1, ACT_SILU);
     dw(p + ".cv3." + ls + ".1.0.conv", e1, d2, ACT_SILU);
@@ -273,11 +267,29 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
     cv(p + ".cv3." + ls + ".2", e2, P.head[l].slice(64, nc_), 1, ACT_NONE);
     if (nk > 0) {
       TView k1 = P.alloc(lv, c4, T), k2 = P.alloc(lv, c4, T);
+      P.cur_lane = P.lanes_enabled() ? 3 * l + 3 : 0;
       cv(p + ".cv4." + ls + ".0.conv", x, k1, 1, ACT_SILU);
       cv(p + ".cv4." + ls + ".1.conv", k1, k2, 1, ACT_SILU);
       cv(p + ".cv4." + ls + ".2", k2, P.head[l].slice(64 + nc_, nk), 1, ACT_NONE);
     }
-  }
+    P.cur_lane = 0;
+  };
+
+
+  TView x16 = P.alloc(P.L[3], c256, T);
+  c3k2("model.16", cat15, x16, c256, false, 0.5, fold15 ? &x13 : nullptr);
+  head_level(0, x16);
+  cv("model.17.conv", x16, cat18.slice(0, c256), 2, ACT_SILU);
+  TView x19 = P.alloc(P.L[4], c512, T);
+  c3k2("model.19", cat18, x19, c512, false, 0.5);
+  head_level(1, x19);
+  cv("model.20.conv", x19, cat21.slice(0, c512), 2, ACT_SILU);
+  TView x22 = P.alloc(P.L[5], c1024, T);
+  c3k2("model.22", cat21, x22, c1024, true, 0.5);
+  head_level(2, x22);
+
+  // ---- Pose head: per level one fp32 record [64 DFL | nc | 3*nkpt] per pixel ---------------------------------------------
+  for (int k = 1; k <= 9; ++k) P.join(k);          // lane 0 continues (decode, NMS) after every tower of every level
 
   P.add_amax_reset(st_);      // first step of every run: max-|value| slots back to their static bounds / zero
 
