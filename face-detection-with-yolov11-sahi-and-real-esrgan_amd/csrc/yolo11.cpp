@@ -119,10 +119,15 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
       const int c_ = c / 2;
       TView cat2 = P.alloc(in.lvl, 2 * c_, T);
       TView a0 = P.alloc(in.lvl, c_, T), a1 = P.alloc(in.lvl, c_, T);
+      const int side = 10;                               // C3k's second branch (one 1x1 conv over b) runs beside the bottleneck chain
+      P.fork(side);
+      P.cur_lane = P.lanes_enabled() ? side : 0;
+      cv(p + ".m.0.cv2.conv", b, cat2.slice(c_, c_), 1, ACT_SILU);
+      P.cur_lane = 0;
       cv(p + ".m.0.cv1.conv", b, a0, 1, ACT_SILU);
       bottleneck(p + ".m.0.m.0", a0, a1, c_);
       bottleneck(p + ".m.0.m.1", a1, cat2.slice(0, c_), c_);
-      cv(p + ".m.0.cv2.conv", b, cat2.slice(c_, c_), 1, ACT_SILU);
+      P.join(side);
       cv(p + ".m.0.cv3.conv", cat2, mo, 1, ACT_SILU);
     }
     cv(p + ".cv2.conv", cat, out, 1, ACT_SILU);
