@@ -84,6 +84,7 @@ _SIGS = {
                                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _p(C.c_int64)]),
     "ffp_sr_plan_state": (C.c_int, [C.c_void_p, _p(C.c_int32), _p(C.c_int32)]),
     "ffp_det_graph_status": (C.c_int, [C.c_void_p, _p(C.c_int32)]),
+    "ffp_det_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),
     "ffp_sr_last_ms": (C.c_int, [C.c_void_p, _p(C.c_float)]),
     "ffp_sr_last_conv_stats": (C.c_int, [C.c_void_p, _p(C.c_double), _p(C.c_float), _p(C.c_int32)]),
     "ffp_sr_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
@@ -284,6 +285,10 @@ class Detector:
         v = C.c_int32(0)
         _check(lib().ffp_det_graph_status(self._h, C.byref(v)))
         return v.value
+
+    def set_lanes(self, mode: int):
+        """0 (default) one stream; 1 head towers and C3k side convs as parallel graph branches (detector-only deployments)."""
+        _check(lib().ffp_det_set_lanes(self._h, int(mode)))
 
     def set_profile(self, on: bool):
         _check(lib().ffp_det_set_profile(self._h, int(on)))

@@ -257,6 +257,15 @@ int ffp_det_stage_dev(ffp_det* d, const uint8_t* d_frame, int H, int W, int chan
   FFP_API_END
 }
 
+int ffp_det_set_lanes(ffp_det* d, int mode) {
+  FFP_API_BEGIN
+  FFP_CHECK(d && mode >= 0 && mode <= 3, FFP_ERR_ARG, "det_set_lanes: mode %d outside [0,3]", mode);
+  FFP_HIP(hipSetDevice(d->eng.device()));
+  FFP_HIP(hipStreamSynchronize(d->eng.stream()));
+  d->eng.set_lanes(mode);
+  FFP_API_END
+}
+
 int ffp_det_graph_status(ffp_det* d, int32_t* out_state) {
   FFP_API_BEGIN
   FFP_CHECK(d && out_state, FFP_ERR_ARG, "null argument");

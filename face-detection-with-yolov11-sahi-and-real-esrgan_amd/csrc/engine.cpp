@@ -161,9 +161,9 @@ Plan::~Plan() {
   for (hipStream_t q : lane_streams) (void)hipStreamDestroy(q);
 }
 
-bool Plan::lanes_enabled() const {
-  static const bool on = [] { const char* e = getenv("FFP_LANES"); return !(e && e[0] == '0'); }();
-  return on;
+int Plan::lanes_env() {
+  static const int m = [] { const char* e = getenv("FFP_LANES"); return e ? atoi(e) : -1; }();
+  return m;
 }
 
 void Plan::fork(int lane) {

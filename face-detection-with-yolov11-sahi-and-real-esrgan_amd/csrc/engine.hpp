@@ -79,7 +79,13 @@ struct Plan {
   // side lanes (FFP_LANES=0: everything stays on lane 0). New steps go to `cur_lane`.
   int cur_lane = 0;
   std::vector<hipStream_t> lane_streams;                 // lane k > 0 -> lane_streams[k - 1]
-  bool lanes_enabled() const;
+  // lanes: 0 off (default: beside the enhancer's stream more overlap costs more than it gains), 1 every branch its
+  // own lane (detector-only deployments), 2 one lane per head level, 3 head level 0 only. The owner sets it before building;
+  // env FFP_LANES overrides it for A/B runs.
+  int lanes = 0;
+  static int lanes_env();                                // FFP_LANES or -1
+  int lane_mode() const { return lanes_env() >= 0 ? lanes_env() : lanes; }
+  bool lanes_enabled() const { return lane_mode() != 0; }
   void fork(int lane);                                   // no-op when lanes are disabled (the steps then run in issue order on lane 0)
   void join(int lane);
   void run_steps(hipStream_t st, bool use_lanes);

@@ -120,14 +120,14 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
       TView cat2 = P.alloc(in.lvl, 2 * c_, T);
       TView a0 = P.alloc(in.lvl, c_, T), a1 = P.alloc(in.lvl, c_, T);
       const int side = 10;                               // C3k's second branch (one 1x1 conv over b) runs beside the bottleneck chain
-      P.fork(side);
-      P.cur_lane = P.lanes_enabled() ? side : 0;
+      if (P.lane_mode() == 1) P.fork(side);
+      P.cur_lane = P.lane_mode() == 1 ? side : 0;
       cv(p + ".m.0.cv2.conv", b, cat2.slice(c_, c_), 1, ACT_SILU);
       P.cur_lane = 0;
       cv(p + ".m.0.cv1.conv", b, a0, 1, ACT_SILU);
       bottleneck(p + ".m.0.m.0", a0, a1, c_);
       bottleneck(p + ".m.0.m.1", a1, cat2.slice(0, c_), c_);
-      P.join(side);
+      if (P.lane_mode() == 1) P.join(side);
       cv(p + ".m.0.cv3.conv", cat2, mo, 1, ACT_SILU);
     }
     cv(p + ".cv2.conv", cat, out, 1, ACT_SILU);
@@ -258,13 +258,15 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
     const std::string p = "model.23";
     const std::string ls = std::to_string(l);
     TView t1 = P.alloc(lv, c2, T), t2 = P.alloc(lv, c2, T);
-    for (int k = 1; k <= 3; ++k) P.fork(3 * l + k);
-    P.cur_lane = P.lanes_enabled() ? 3 * l + 1 : 0;
+    const int lm = P.lane_mode();
+    auto tower_lane = [&](int k) { return lm == 1 ? 3 * l + k : lm == 2 ? 3 * l + 1 : (lm == 3 && l == 0) ? 1 : 0; };
+    for (int k = 1; k <= 3; ++k) if (lm == 1 || k == 1) P.fork(tower_lane(k));
+    P.cur_lane = tower_lane(1);
     cv(p + ".cv2." + ls + ".0.conv", x, t1, 1, ACT_SILU);
     cv(p + ".cv2." + ls + ".1.conv", t1, t2, 1, ACT_SILU);
     cv(p + ".cv2." + ls + ".2", t2, P.head[l].slice(0, 64), 1, ACT_NONE);
     TView d1 = P.alloc(lv, chs[l], T), e1 = P.alloc(lv, c3, T), d2 = P.alloc(lv, c3, T), e2 = P.alloc(lv, c3, T);
-    P.cur_lane = P.lanes_enabled() ? 3 * l + 2 : 0;
+    P.cur_lane = tower_lane(2);
     dw(p + ".cv3." + ls + ".0.0.conv", x, d1, ACT_SILU);
     cv(p + ".cv3." + ls + ".0.1.conv", d1, e1, 1, ACT_SILU);
     dw(p + ".cv3." + ls + ".1.0.conv", e1, d2, ACT_SILU);
@@ -272,7 +274,7 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
     cv(p + ".cv3." + ls + ".2", e2, P.head[l].slice(64, nc_), 1, ACT_NONE);
     if (nk > 0) {
       TView k1 = P.alloc(lv, c4, T), k2 = P.alloc(lv, c4, T);
-      P.cur_lane = P.lanes_enabled() ? 3 * l + 3 : 0;
+      P.cur_lane = tower_lane(3);
       cv(p + ".cv4." + ls + ".0.conv", x, k1, 1, ACT_SILU);
       cv(p + ".cv4." + ls + ".1.conv", k1, k2, 1, ACT_SILU);
       cv(p + ".cv4." + ls + ".2", k2, P.head[l].slice(64 + nc_, nk), 1, ACT_NONE);
@@ -294,7 +296,8 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
   head_level(2, x22);
 
   // ---- Pose head: per level one fp32 record [64 DFL | nc | 3*nkpt] per pixel ---------------------------------------------
-  for (int k = 1; k <= 9; ++k) P.join(k);          // lane 0 continues (decode, NMS) after every tower of every level
+  for (int k = 1; k <= 9; ++k)                      // lane 0 continues (decode, NMS) after every tower of every level
+    if (P.lane_mode() == 1 || (P.lane_mode() == 2 && k % 3 == 1) || (P.lane_mode() == 3 && k == 1)) P.join(k);
 
   P.add_amax_reset(st_);      // first step of every run: max-|value| slots back to their static bounds / zero
 
@@ -354,6 +357,7 @@ DetPlan* DetEngine::plan_for(const std::vector<TileGeom>& g) {
   if (it == plans_.end()) {
     if (plans_.size() >= 8) plans_.clear();     // bound the cache; plans are cheap to rebuild
     std::unique_ptr<DetPlan> p(new DetPlan());
+    p->lanes = lanes_;
     std::vector<int> hs, ws;
     for (const TileGeom& t : g) { hs.push_back(t.lb.net_h); ws.push_back(t.lb.net_w); }
     build_plan(*p, hs, ws);

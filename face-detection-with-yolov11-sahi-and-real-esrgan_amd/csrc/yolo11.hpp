@@ -31,6 +31,8 @@ class DetEngine {
   ~DetEngine();
 
   int det_stride() const { return 6 + 3 * nkpt_; }
+  // Plan::lanes of every plan built from now on (cached plans are dropped): parallel graph branches for the head towers and C3k
+  void set_lanes(int mode) { if (mode != lanes_) { lanes_ = mode; plans_.clear(); } }
   int device() const { return device_; }
   hipStream_t stream() const { return st_; }
   int nc() const { return nc_; }
@@ -69,6 +71,7 @@ class DetEngine {
   std::map<std::string, PackedConv> convs_;
   std::map<std::vector<int>, std::unique_ptr<DetPlan>> plans_;
   std::vector<TileGeom> geom_last_;
+  int lanes_ = 0;
   int device_ = 0, nc_ = 1, nkpt_ = 5;
   char scale_ = 's';
   DType dt_ = F32;

@@ -237,6 +237,8 @@ class FramePipeline:
         self.dev = torch.device("cuda", device)
         self.det = _lib.Detector(det_weights, arch=arch, device=device, precision=det_precision)
         self.sr = _lib.Enhancer(sr_weights, 4, 23, device=device, half=sr_half) if (cfg.sr_crops > 0 and sr_weights is not None) else None
+        if self.sr is None:
+            self.det.set_lanes(1)       # detection only (BASELINE config 2): nothing runs beside the detector, let its branches overlap
         self.stride = self.det.stride
         self._bufs = {}
         self._layouts = {}

@@ -204,6 +204,11 @@ int ffp_sr_plan_state(ffp_sr* s, int32_t* out_plans_built, int32_t* out_last_gra
 /* hipGraph state of the plan the detector's last call ran: 1 replayed a captured graph, 0 not captured yet (first runs of a
  * plan are eager), -1 capture failed and the plan keeps launching eagerly (also reported once on stderr). */
 int ffp_det_graph_status(ffp_det* d, int32_t* out_state);
+/* Parallel branches in the detector's captured launch graph (no counterpart in the reference, which runs one layer at a time:
+ * /root/reference/utils/yolo_wrapper.py:74-80 hands the whole forward pass to one call). mode 0 (default): one stream;
+ * 1: the head's nine towers and C3k's side convs run as parallel graph branches (3-5 % faster when the detector has the device
+ * to itself, slower when an enhancer stream runs beside it); 2 / 3: coarser variants for A/B. Drops the cached plans. */
+int ffp_det_set_lanes(ffp_det* d, int mode);
 
 /* ---------------------------------------------------------------------------------------------------------
  * single-operator entry points (layer-wise parity tests; host NHWC fp32 in/out, computed on `device` in `precision`)

@@ -159,3 +159,25 @@ def test_stem_fused_into_first_conv_runs_and_matches_oracle(gpu_lib, order):
         np.testing.assert_allclose(o[4], r[4], atol=2e-4, rtol=0)
         np.testing.assert_allclose(o[:4], r[:4], atol=2e-2, rtol=0)
         np.testing.assert_allclose(o[5:], r[5:], atol=2e-2, rtol=1e-4)
+
+
+def test_lanes_parallel_graph_branches_change_nothing(gpu_lib):
+    """ffp_det_set_lanes(1): the head's towers and C3k's side convs become parallel branches of the captured graph. Same kernels,
+    same operands, disjoint outputs: the raw head outputs must be bit-identical to the single-stream plan, on the eager first
+    run and on graph replays, and the graph must still be captured."""
+    from ffp_amd import synth
+    W = synth.yolo11_pose_weights("s")
+    frame = synth.synthetic_frame(300, 420, seed=41)
+    tiles = [(0, 0, 256, 256), (164, 44, 420, 300), (0, 0, 420, 300)]
+    det = gpu_lib.Detector(W, arch="s", precision=gpu_lib.PREC_F32X3)
+    base = det.forward_raw(frame, tiles, 256)
+    det.set_lanes(1)
+    for it in range(4):
+        outs = det.forward_raw(frame, tiles, 256)
+        for a, b in zip(base, outs):
+            assert np.array_equal(a, b), it
+    assert det.graph_status() == 1
+    det.set_lanes(0)
+    outs = det.forward_raw(frame, tiles, 256)
+    for a, b in zip(base, outs):
+        assert np.array_equal(a, b)
