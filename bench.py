@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--cpu-sample", action="store_true", help="CPU baseline on a bounded sample (3 slices + 3 crops) instead of one whole frame")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--secondary-steps", type=int, default=20)
+    ap.add_argument("--sr-exclusive", action="store_true", help="experiment: wait for every SR batch before the next detection group (no overlap of the two streams)")
     return ap.parse_args()
 
 
@@ -300,6 +301,8 @@ class Runner:
                     self.drain_sr()
                     pipe.sr.set_profile(True)
                 self.flush_sr(slot=(i // self.SB) & 1)
+                if a.sr_exclusive:
+                    self.drain_sr()                                                      # experiment: the enhancer never runs beside the detector
                 if prof:
                     self.drain_sr()
                     torch.cuda.synchronize(self.dev)
