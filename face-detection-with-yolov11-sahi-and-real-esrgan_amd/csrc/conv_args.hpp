@@ -48,7 +48,7 @@ struct ConvArgs {
   const void* st_w;                  // stem weights as MFMA A fragments [chunk][hi|lo][64 lanes] x 16 B (stem_pack_kernel)
   const float* st_bias;
   int st_W;                          // frame width
-  int st_bytes;                      // frame size in bytes (range check of the loader's dword reads)
+  long long st_bytes;                // frame size in bytes, rounded up to whole dwords (range check of the loader's dword reads)
   float st_scale;                    // 1 / (power of two the packed stem weights were multiplied by)
 };
 

@@ -358,7 +358,13 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
       if (plain) {
         // lane (n, kb) reads the 9 bytes of window row min(kb, 2) as three aligned dwords through a range-checked resource (a dword
         // wholly outside the frame reads zero); kb = 3 takes byte 8 of the three rows from its neighbours' registers
-        const auto rs_f = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<unsigned char*>(a.st_frame)), 0, a.st_bytes, 0x00020000);
+        // (the resource starts at the item's first frame row, so a stack of frames of any size stays within its 32-bit offsets)
+        const long long row_b = (long long)Lb.y0 * a.st_W * 3;
+        const long long row0 = row_b & ~3ll;                 // dword-aligned like the frame itself
+        const int skew = (int)(row_b - row0);
+        const long long left = a.st_bytes - row0;
+        const auto rs_f = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<unsigned char*>(a.st_frame) + row0), 0,
+                                                            (int)(left < 0x7FFFFFFCll ? left : 0x7FFFFFFCll), 0x00020000);
         const int r = kb < 3 ? kb : 2;
         unsigned w0[SGW], w1[SGW], w2[SGW];
 #pragma unroll
@@ -366,7 +372,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
           int q, sy, sx;
           const bool inmap = geom(j, q, sy, sx);
           const int ny = 2 * sy - 1 + r;
-          const int A = ((Lb.y0 + ny) * a.st_W + Lb.x0 + 2 * sx - 1) * 3;
+          const int A = (ny * a.st_W + Lb.x0 + 2 * sx - 1) * 3 + skew;
           const unsigned base = (inmap && (unsigned)ny < (unsigned)Hn) ? (unsigned)(A & ~3) : OOB;
           w0[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_f, base, 0, 0);
           w1[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_f, base == OOB ? OOB : base + 4u, 0, 0);
@@ -378,7 +384,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
           const bool inmap = geom(j, q, sy, sx);
           const int ny = 2 * sy - 1 + r;
           const bool rowok = inmap && (unsigned)ny < (unsigned)Hn;
-          const unsigned al = (unsigned)(((Lb.y0 + ny) * a.st_W + Lb.x0 + 2 * sx - 1) * 3) & 3u;
+          const unsigned al = (unsigned)((ny * a.st_W + Lb.x0 + 2 * sx - 1) * 3 + skew) & 3u;
           unsigned d0 = __builtin_amdgcn_alignbyte(w1[j], w0[j], al), d1 = __builtin_amdgcn_alignbyte(w2[j], w1[j], al);
           unsigned b8 = __builtin_amdgcn_alignbyte(0u, w2[j], al) & 0xFFu;
           if (sx == 0) d0 &= 0xFF000000u;                    // window column -1: the stem's own zero padding
@@ -928,8 +934,7 @@ void launch_stem_conv(const uint8_t* d_frame, int H, int W, const DevBuf& d_imgs
   ConvArgs a = make_conv_args(conv);
   a.in = nullptr;                                  // never read
   a.st_frame = d_frame; a.st_W = W;
-  FFP_CHECK((long long)H * W * 3 < (1ll << 31), FFP_ERR_ARG, "stem-fused conv: frame of %dx%d exceeds the 2 GiB the loader addresses", W, H);
-  a.st_bytes = (H * W * 3 + 3) & ~3;              // whole dwords: the last pixel's dword may end up to 3 bytes past the frame (inside the allocation granule)
+  a.st_bytes = ((long long)H * W * 3 + 3) & ~3ll;    // whole dwords: the last pixel's dword may end up to 3 bytes past the frame (inside the allocation granule)
   a.st_imgs = d_imgs.as<LetterboxImg>();
   a.st_tab = stem.in.lvl->d_tab.as<int4>();
   a.st_w = stem_w.p;

@@ -380,6 +380,7 @@ DetPlan* DetEngine::prepare(const uint8_t* d_frame, int H, int W, int chan_order
   const int flip = chan_order == FFP_CHAN_AS_BGR ? 1 : 0;
   if (prof.enabled) prof.begin();
   if (P->fused_stem_conv) {
+    if (!P->tuned) P->tune(st_);      // the tuner's timing launches raise max-|value| slots from stale buffers: before the reset, never after it
     P->reset_fn(st_);
     const int slot = prof.enabled ? prof.open(st_) : -1;
     launch_stem_conv(d_frame, H, W, P->d_lb, P->stem_w[flip], P->stem, P->stemconv, st_);

@@ -181,3 +181,22 @@ def test_lanes_parallel_graph_branches_change_nothing(gpu_lib):
     outs = det.forward_raw(frame, tiles, 256)
     for a, b in zip(base, outs):
         assert np.array_equal(a, b)
+
+
+def test_frames_stack_beyond_2_gib(gpu_lib):
+    """A stack of frames larger than 2 GiB (the harness stacks the frames of a detection group into one tall frame): crops near its end
+    must read the same pixels as the same crops of a small frame — the stem-fused loader rebases its 32-bit buffer offsets per item."""
+    from ffp_amd import synth
+    W = synth.yolo11_pose_weights("s")
+    det = gpu_lib.Detector(W, arch="s", precision=gpu_lib.PREC_F32X3)
+    band = synth.synthetic_frame(600, 4096, seed=5)
+    rows = 180_000                                            # 180,000 x 4096 x 3 B = 2.21 GB
+    big = np.zeros((rows, 4096, 3), np.uint8)
+    y0 = rows - 600
+    big[y0:] = band
+    tiles_small = [(0, 0, 512, 512), (3584, 88, 4096, 600), (1001, 43, 1513, 555), (2000, 100, 2300, 400)]    # native slices + an up-scaled crop
+    tiles_big = [(x0, y0 + a, x1, y0 + b) for x0, a, x1, b in tiles_small]
+    ref = det.forward_raw(band, tiles_small, 512)
+    out = det.forward_raw(big, tiles_big, 512)
+    for t, a, b in zip(tiles_small, ref, out):                # same items, same batch mates: the same bits
+        assert np.array_equal(a, b), t
