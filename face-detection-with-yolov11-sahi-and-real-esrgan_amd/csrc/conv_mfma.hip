@@ -319,7 +319,8 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
   // the fp32-grade sum; lane (n, g = kb) ends with channels 4g..4g+3 of pixel n: bias, SiLU, zero outside the stem map (the conv's
   // own zero padding), then the same split records the fp32 loader writes. Chunk 0 goes to the stage, chunk 1 waits in registers.
   constexpr int SG = (NPIX + 15) / 16, SGW = (SG + 3) / 4;
-  uint2 s1h[STEM ? SGW : 1], s1l[STEM ? SGW : 1];
+  constexpr int SCH = NIW;                       // 16-channel chunks of the stem output = input chunks of this conv (YOLO11s: 2 with 64 outputs, YOLO11n: 1 with 32; launch_stem_conv checks)
+  uint2 s1h[STEM && SCH == 2 ? SGW : 1], s1l[STEM && SCH == 2 ? SGW : 1];
   auto stem_fill = [&](unsigned char* buf) {
     if constexpr (STEM) {
       static_assert(!STEM || (KC == 16 && SPLIT && KS == 3 && STRIDE == 2), "stem-fused loader: split 3x3 stride 2, 16-channel chunks");
@@ -332,12 +333,15 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
       const int Hn = nt.y, Wn = nt.z;
       const uint4* swp = reinterpret_cast<const uint4*>(a.st_w) + lane;
       union FU { uint4 u; f16x8 h; };
-      FU afr[2][2];
+      static_assert(!STEM || SCH == 1 || SCH == 2, "stem-fused loader: one or two 16-channel chunks");
+      FU afr[SCH][2];
+      float4 sb[SCH];
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < SCH; ++c) {
 #pragma unroll
         for (int part = 0; part < 2; ++part) afr[c][part].u = swp[(c * 2 + part) * 64];
-      const float4 sb[2] = {*reinterpret_cast<const float4*>(a.st_bias + 4 * kb), *reinterpret_cast<const float4*>(a.st_bias + 16 + 4 * kb)};
+        sb[c] = *reinterpret_cast<const float4*>(a.st_bias + 16 * c + 4 * kb);
+      }
       // B operands of all groups first (their loads in flight together), then the arithmetic
       uint4 bq[SGW];
       const f16x2 k1024 = {(_Float16)1024.f, (_Float16)1024.f};
@@ -423,7 +427,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
         FU bfr;
         bfr.u = bq[j];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < SCH; ++c) {
           f32x4 d = {0.f, 0.f, 0.f, 0.f};
           d = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[c][0].h, bfr.h, d, 0, 0, 0);
           d = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[c][1].h, bfr.h, d, 0, 0, 0);
@@ -439,7 +443,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
               *reinterpret_cast<uint2*>(rec) = hi;
               *reinterpret_cast<uint2*>(rec + KC * 2) = lo;
             }
-          } else {
+          } else if constexpr (SCH == 2) {
             s1h[j] = hi; s1l[j] = lo;
           }
         }
@@ -447,7 +451,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
     }
   };
   auto stem_flush = [&](unsigned char* buf) {
-    if constexpr (STEM) {
+    if constexpr (STEM && SCH == 2) {
       const int n = lane & 15, kb = lane >> 4;
 #pragma unroll
       for (int j = 0; j < SGW; ++j) {
@@ -892,7 +896,8 @@ static const void* zero_block() {
 
 // ---- stem fused into the first MFMA conv (conv_mfma_kernel<X3, 3, 2, 4, 1, 1, 2, 16, true>) ------------------------------------
 namespace {
-using StemG = Geo<X3, 3, 2, 4, 1, 1, 2, 16>;
+using StemG = Geo<X3, 3, 2, 4, 1, 1, 2, 16>;       // YOLO11s: 32 stem channels -> 64
+using StemGn = Geo<X3, 3, 2, 4, 1, 1, 1, 16>;      // YOLO11n: 16 -> 32
 constexpr float kStemWScale = 4096.f;      // the packed stem weights are w / 255 * 2^12: fp16 normal range for every weight that matters
 
 // fp32 stem weights [tap][net channel][cout] -> A fragments of v_mfma_f32_16x16x32_f16 in the loader's k order (see stem_fill):
@@ -918,8 +923,8 @@ bool stem_conv_eligible(const ConvOp& stem, const ConvOp& conv) {
   const PackedConv& ps = *stem.pc;
   const PackedConv& pc = *conv.pc;
   static const bool off = [] { const char* e = getenv("FFP_NO_STEM_FUSE"); return e && e[0] == '1'; }();
-  return !off && conv_direct_eligible(stem) && ps.dt == F32 && stem.stride == 2 && stem.act == ACT_SILU && ps.cout == 32 && ps.w_direct.p != nullptr &&
-         pc.split && pc.dt == F32 && pc.k == 3 && conv.stride == 2 && pc.cin == 32 && pc.cout_pad == 64 && !conv.up && !conv.has_res1 && !conv.has_res2 &&
+  return !off && conv_direct_eligible(stem) && ps.dt == F32 && stem.stride == 2 && stem.act == ACT_SILU && (ps.cout == 32 || ps.cout == 16) && ps.w_direct.p != nullptr &&
+         pc.split && pc.dt == F32 && pc.k == 3 && conv.stride == 2 && pc.cin == ps.cout && pc.cout_pad == 2 * ps.cout && !conv.up && !conv.has_res1 && !conv.has_res2 &&
          !conv.has_up2 && conv.in.lvl == stem.out.lvl && conv.in.amax != nullptr && !conv.out.lvl->capacity();
 }
 
@@ -941,10 +946,12 @@ void launch_stem_conv(const uint8_t* d_frame, int H, int W, const DevBuf& d_imgs
   a.st_bias = stem.pc->bias.as<float>();
   a.st_scale = 1.0f / kStemWScale;
   int n_tiles = 0;
+  static_assert(StemG::TH == StemGn::TH, "one tile table for both");
   a.tiles = conv.out.lvl->tile_table(StemG::TH, &n_tiles, &a.n_tiles_dev, st);
   a.n_nblk = 1;
   if (n_tiles == 0) return;
-  hipLaunchKernelGGL((conv_mfma_kernel<X3, 3, 2, 4, 1, 1, 2, 16, true>), dim3(n_tiles), dim3(256), StemG::LDS, st, a);
+  if (stem.pc->cout == 32) hipLaunchKernelGGL((conv_mfma_kernel<X3, 3, 2, 4, 1, 1, 2, 16, true>), dim3(n_tiles), dim3(256), StemG::LDS, st, a);
+  else hipLaunchKernelGGL((conv_mfma_kernel<X3, 3, 2, 4, 1, 1, 1, 16, true>), dim3(n_tiles), dim3(256), StemGn::LDS, st, a);
   FFP_HIP(hipGetLastError());
 }
 
@@ -959,6 +966,7 @@ void conv_kernels_init() {
   Family<_Float16, 1, 1>::init(); Family<_Float16, 3, 1>::init(); Family<_Float16, 3, 2>::init();
   Family<X3, 1, 1>::init(); Family<X3, 3, 1>::init(); Family<X3, 3, 2>::init();
   FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<X3, 3, 2, 4, 1, 1, 2, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, StemG::LDS));
+  FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<X3, 3, 2, 4, 1, 1, 1, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, StemGn::LDS));
   done = true;
 }
 

@@ -131,18 +131,19 @@ def test_f32x3_detector_with_bn_fold_like_channel_scales(gpu_lib, K):
         assert e3[:5].max() <= max(3 * e1[:5].max(), 5e-3), (K, e3[:5].max(), e1[:5].max())
 
 
+@pytest.mark.parametrize("arch", ["s", "n"])
 @pytest.mark.parametrize("order", [0, 1], ids=["as_bgr", "as_rgb"])
-def test_stem_fused_into_first_conv_runs_and_matches_oracle(gpu_lib, order):
-    """YOLO11s in the default arithmetic computes model.0 inside model.1's loader (conv_mfma_kernel<..., STEM>, no stored stem
+def test_stem_fused_into_first_conv_runs_and_matches_oracle(gpu_lib, order, arch):
+    """YOLO11s / YOLO11n in the default arithmetic compute model.0 inside model.1's loader (conv_mfma_kernel<..., STEM>, no stored stem
     output). The profile must name the fused launch (so this cannot pass on the two-kernel path), and the raw head outputs must
     meet the usual bars for a native-size slice (the dword fast path, image border on every side), an interior slice, a
     down-scaled full frame (resize + letterbox padding), an up-scaled crop and an odd-offset slice, in both channel orders."""
     from ffp_amd import synth
     from oracle import ultra_post
     from oracle.yolo11_ref import Yolo11PoseRef
-    W = synth.yolo11_pose_weights("s")
-    ref = Yolo11PoseRef(W, "s")
-    det = gpu_lib.Detector(W, arch="s", precision=gpu_lib.PREC_F32X3)
+    W = synth.yolo11_pose_weights(arch)
+    ref = Yolo11PoseRef(W, arch)
+    det = gpu_lib.Detector(W, arch=arch, precision=gpu_lib.PREC_F32X3)
     frame = synth.synthetic_frame(301, 421, seed=33)              # 301 x 421 x 3 bytes is not a whole number of dwords
     tiles = [(0, 0, 256, 256), (165, 45, 421, 301), (0, 0, 421, 301), (30, 40, 190, 140), (5, 7, 261, 263)]
     det.set_profile(True)
