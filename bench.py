@@ -419,10 +419,17 @@ def main():
         ss, sw = max(2, args.secondary_steps), max(2, min(args.warmup, 4))
 
         def sec(name, **kw):
-            r = Runner(args, ctx, pipe=pipe, **kw)
-            d = r.timed(sw, ss, profile_last=False)
-            secondary[name] = {"value": round(r.B * ss / d, 3), "unit": "frames/s", "ms_per_step": round(d / ss * 1e3, 3), "steps": ss, "workload": r.describe(),
-                               "frames_per_step": r.B, "gathered": bool(r.state.get("gathered", False))}
+            # a secondary row must never cost the headline line: a failure (e.g. out of memory in the 4x-larger imgsz-1024 plan) is
+            # reported in place of the row; the rows that follow still run
+            r = None
+            try:
+                r = Runner(args, ctx, pipe=pipe, **kw)
+                d = r.timed(sw, ss, profile_last=False)
+                secondary[name] = {"value": round(r.B * ss / d, 3), "unit": "frames/s", "ms_per_step": round(d / ss * 1e3, 3), "steps": ss, "workload": r.describe(),
+                                   "frames_per_step": r.B, "gathered": bool(r.state.get("gathered", False))}
+            except Exception as e:      # noqa: BLE001
+                secondary[name] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+                print(f"[bench] secondary row {name} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
             return r
 
         sec("frames_resident_in_hbm", resident=True)
@@ -434,10 +441,11 @@ def main():
                 sec("with_allgather", exchange="always")
             if main_r.B != 1:
                 r = sec("one_frame_across_ranks", frames_per_step=1, exchange="auto", det_batch=1)      # ONE frame's 61 items over the ranks
-                secondary["one_frame_across_ranks"]["scaling"] = "strong"
+                secondary["one_frame_across_ranks"]["scaling"] = "strong"        # (key exists whether or not the row failed)
         if args.sr_crops > 0 and world == 1:
             r = sec("with_jpeg_decode_and_encode", jpeg_io=True)
-            secondary["with_jpeg_decode_and_encode"].update({"note": "frames arrive as JPEG (quality 95, 4:2:0) and are decoded into device memory; enhanced crops leave as JPEG files "
+            if r is not None and secondary["with_jpeg_decode_and_encode"].get("value") is not None:
+              secondary["with_jpeg_decode_and_encode"].update({"note": "frames arrive as JPEG (quality 95, 4:2:0) and are decoded into device memory; enhanced crops leave as JPEG files "
                                                                      "(quality 95, byte-identical to cv2.imwrite); reported separately as SURVEY §8(d) prescribes",
                                                              "jpeg_bytes_in_per_frame": int(r.jpeg_bytes_in / max(1, r.frames_in)), "jpeg_bytes_out_per_frame": int(r.jpeg_bytes_out / max(1, r.frames_in))})
         if args.imgsz != 1024:
