@@ -20,7 +20,7 @@ _CALIB = None
 
 
 def _calib(key: str) -> Dict[str, float]:
-    """Per-conv scalar multipliers (tools/make_synth_calibration.py) standing in for trained BatchNorm statistics."""
+    """Per-conv scalar multipliers (tests/golden/make_synth_calibration.py) standing in for trained BatchNorm statistics."""
     global _CALIB
     if _CALIB is None:
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "synth_calib.json")

@@ -3,7 +3,7 @@ checkpoint — each convolution's pre-activation output has unit standard deviat
 random-init networks used for benchmarks/parity are numerically well conditioned (no saturated scores, no
 exploding activations). Uses the CPU oracle as the forward pass; the product package only reads the JSON.
 
-    python tools/make_synth_calibration.py
+    python tests/golden/make_synth_calibration.py
 """
 import json
 import os
@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ffp_amd  # noqa: E402
 from ffp_amd import synth  # noqa: E402
