@@ -159,6 +159,10 @@ class Runner:
             self.jpegs = [_lib.jpeg_encode(f, 95, bgr=False) for f in ctx["host_frames"]]
             self.pool = ThreadPoolExecutor(max_workers=8)
             self.jpeg_bytes_in = self.jpeg_bytes_out = 0
+        # frame slots: a ring deep enough that a slot is never refilled while queued crops (held until SB frames are together) or the
+        # SR batch in flight (whose crop gather reads the frames asynchronously on the enhancer's stream, include/ffp.h: d_frame stays
+        # untouched until ffp_sr_wait) still read it; upload() also waits for the batch in flight if it ever meets its slot
+        self.nslots = -(-self.SB // (self.DB * self.B)) + 3
         self.host_supers, self.slots = {}, {}
         self.state, self.pending, self.queue, self.group = {}, {}, [], {}
         self.sr_px = 0
@@ -178,11 +182,17 @@ class Runner:
         variant = gi % len(self.ctx["host_frames"])
         if self.resident:
             key = ("res", nf, variant)
+            self.state["slot_key"] = key
             if key not in self.slots:
                 self.slots[key] = self.host_super(nf, variant).to(self.dev)
                 torch.cuda.synchronize(self.dev)
             return self.slots[key], None
-        key = (nf, gi % 3)
+        key = (nf, gi % self.nslots)
+        if any(k == key for k, _, _ in self.queue):
+            raise RuntimeError("frame slot ring too small: a slot with queued crops would be overwritten")
+        if key in self.pending.get("slots", ()):
+            self.drain_sr()                            # the SR batch in flight still gathers crops from this slot
+        self.state["slot_key"] = key
         if key not in self.slots:
             self.slots[key] = torch.empty((nf * self.H, self.W, 3), dtype=torch.uint8, device=self.dev)
             torch.cuda.synchronize(self.dev)
@@ -226,6 +236,7 @@ class Runner:
         if self.pending:
             self.pipe.wait_sr()
             out = self.pending.pop("out")
+            self.pending.pop("slots", None)
             if self.jpeg_io:
                 offs, hs, ws = self.pending.pop("meta")
                 files = self._lib.jpeg_encode_batch_dev(out.data_ptr(), offs, hs, ws, 95, bgr=True, device=self.ctx["local_rank"])     # enhanced crops -> .jpg bytes on the host
@@ -239,12 +250,14 @@ class Runner:
         if not self.queue:
             return
         self.drain_sr()
-        q = [x for x in self.queue if len(x[1])]
+        q = [x[1:] for x in self.queue if len(x[2])]
+        keys = {x[0] for x in self.queue if len(x[2])}
         self.queue.clear()
         if not q:
             return
         out, offs = self.pipe.enhance_crops_multi([x[0] for x in q], self.H, self.W, [x[1] for x in q], slot=slot)
         self.pending["out"] = out
+        self.pending["slots"] = keys
         if self.jpeg_io:
             bx = np.concatenate([x[1] for x in q], 0).astype(np.int64)
             bx = np.stack([np.clip(bx[:, 0], 0, self.W), np.clip(bx[:, 1], 0, self.H), np.clip(bx[:, 2], 0, self.W), np.clip(bx[:, 3], 0, self.H)], 1)   # as the library clamps
@@ -263,8 +276,10 @@ class Runner:
         torch, pipe, a = self.torch, self.pipe, self.args
         B, H, W = self.B, self.H, self.W
         sf, ev = self.group.pop("next")
+        slot_key = self.group.pop("next_key")
         if nxt is not None:
             self.group["next"] = self.upload(gi + 1, B * nxt[1])          # overlaps this group's detection
+            self.group["next_key"] = self.state["slot_key"]
         if ev is not None:
             ev.synchronize()
         if profile:
@@ -294,7 +309,7 @@ class Runner:
                     if spread:                                                          # crops of ONE frame over the ranks: LPT by area
                         own = self.pipeline.lpt_assign((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]), self.world) == self.rank
                         boxes = boxes[own]
-                    self.queue.append((sf[f * H:(f + 1) * H], boxes))
+                    self.queue.append((slot_key, sf[f * H:(f + 1) * H], boxes))
             if a.sr_crops > 0 and (len(self.queue) >= self.SB or last):
                 prof = self.prof_flush is not None and self.flush_no == self.prof_flush     # the kernel times of ONE whole SR batch
                 if prof:
@@ -319,6 +334,7 @@ class Runner:
         self.prof_flush = (max(n_full, 1) - 1 if n_flush else None) if profile_last else None
         self.flush_no = 0
         self.group["next"] = self.upload(0, self.B * gs[0][1])
+        self.group["next_key"] = self.state["slot_key"]
         for gi, (g0, gsz) in enumerate(gs):
             self.run_group(gi, g0, gsz, n_steps, gs[gi + 1] if gi + 1 < len(gs) else None, profile_last and gi == len(gs) - 1)
         self.flush_sr(slot=0)

@@ -66,5 +66,32 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return OUT
 
 
+ASAN_SOURCES = ["common.cpp", "weights.cpp", "jpeg_dec.cpp", "asan_host_check.cpp"]
+ASAN_OUT = os.path.join(CSRC, "build", "asan_host_check")
+
+
+def build_asan(verbose: bool = True) -> str:
+    """Host-only AddressSanitizer + UBSan build of the parsers of untrusted bytes (FFPW containers, JPEG markers and Huffman
+    tables) with their robustness driver (csrc/asan_host_check.cpp). No device code; runs on a CPU-only box."""
+    clang = os.path.join(os.path.dirname(os.path.realpath(_hipcc())), "..", "lib", "llvm", "bin", "clang++")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang++"
+    os.makedirs(os.path.dirname(ASAN_OUT), exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in ASAN_SOURCES]
+    if os.path.exists(ASAN_OUT) and os.path.getmtime(ASAN_OUT) > max(max(os.path.getmtime(s) for s in srcs), _newest_header()):
+        return ASAN_OUT
+    cmd = [clang, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", *srcs, "-o", ASAN_OUT, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"sanitizer build failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {ASAN_OUT}")
+    return ASAN_OUT
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--asan" in sys.argv:
+        build_asan()
+    else:
+        build(force="--force" in sys.argv)

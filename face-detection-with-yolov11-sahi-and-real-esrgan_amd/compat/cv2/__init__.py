@@ -6,8 +6,9 @@ re-exports it untouched. Drawing primitives are not provided (utils.visualizatio
 
 `.jpg` files go through this build's JPEG codec on the GPU (csrc/jpeg.hip: ffp_jpeg_decode / ffp_jpeg_encode) whenever a device is
 visible; its output is byte-identical (files) and pixel-identical (decoded arrays) to the libjpeg-turbo inside OpenCV and Pillow
-(tests/test_gpu_jpeg.py), so the choice changes the time, not one bit of the result. Files the device codec does not read
-(progressive JPEG) and machines without a GPU use Pillow, and say so once on stderr.
+(tests/test_gpu_jpeg.py) for YCbCr / grayscale baseline files, so the choice changes the time, not one bit of the result. Files the
+device codec does not read (progressive, RGB-coded with Adobe transform 0 or R/G/B component ids) and machines without a GPU use
+Pillow, and say so once on stderr. Like `cv2.imread`, `imread` applies the EXIF orientation tag (not with IMREAD_UNCHANGED).
 """
 import importlib.machinery
 import importlib.util
@@ -61,21 +62,50 @@ else:
     def _is_jpeg(path):
         return os.path.splitext(str(path))[1].lower() in (".jpg", ".jpeg")
 
-    def imread(path, flags=IMREAD_COLOR):
-        """HxWx3 uint8 BGR, or None when the file cannot be read (OpenCV's convention: no exception)."""
+    def _exif_orientation(path):
+        """EXIF orientation tag (1..8; 1 = as stored). Reads the APP1 segment only, no pixel decoding."""
         try:
+            with Image.open(path) as im:
+                o = int(im.getexif().get(0x0112, 1))
+            return o if 1 <= o <= 8 else 1
+        except Exception:
+            return 1
+
+    def _oriented(a, o):
+        """What OpenCV's imread does with the EXIF orientation unless IMREAD_IGNORE_ORIENTATION / IMREAD_UNCHANGED is set."""
+        if o == 2:
+            a = a[:, ::-1]
+        elif o == 3:
+            a = a[::-1, ::-1]
+        elif o == 4:
+            a = a[::-1]
+        elif o == 5:
+            a = a.transpose(1, 0, 2)
+        elif o == 6:
+            a = a.transpose(1, 0, 2)[:, ::-1]
+        elif o == 7:
+            a = a.transpose(1, 0, 2)[::-1, ::-1]
+        elif o == 8:
+            a = a.transpose(1, 0, 2)[::-1]
+        return np.ascontiguousarray(a)
+
+    def imread(path, flags=IMREAD_COLOR):
+        """HxWx3 uint8 BGR with the EXIF orientation applied (OpenCV's default), or None when the file cannot be read (OpenCV's
+        convention: no exception)."""
+        try:
+            o = _exif_orientation(path) if flags != IMREAD_UNCHANGED else 1
             if _is_jpeg(path):
                 codec = _gpu_codec()
                 if codec:
                     with open(path, "rb") as fh:
                         data = fh.read()
                     try:
-                        return codec.jpeg_decode(data, bgr=True)
-                    except codec.FfpError as e:               # e.g. a progressive file
+                        return _oriented(codec.jpeg_decode(data, bgr=True), o)
+                    except codec.FfpError as e:               # e.g. a progressive or an RGB-coded (Adobe transform 0) file
                         _tell(str(e))
                 else:
                     _tell("no GPU visible")
-            return np.asarray(Image.open(path).convert("RGB"))[..., ::-1].copy()
+            return _oriented(np.asarray(Image.open(path).convert("RGB"))[..., ::-1], o)
         except Exception:
             return None
 

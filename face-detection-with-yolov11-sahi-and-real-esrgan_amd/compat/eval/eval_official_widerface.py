@@ -54,8 +54,10 @@ class OfficialWiderFaceEvaluator:
 
     # ---- inference (:166-255), SAHI or plain predict; boxes as x, y, w, h, score -------------------------------------------------
     def _run_single_inference(self, img_path):
-        from PIL import Image
-        img = np.asarray(Image.open(img_path).convert("RGB"))
+        import cv2                                                     # a real OpenCV if present, else this build's shim: BGR either way (:168)
+        img = cv2.imread(str(img_path))
+        if img is None:
+            return np.array([])
         if self.use_sahi:
             from sahi.predict import get_sliced_prediction
             cfg = dict(self.sahi_config)
@@ -67,11 +69,17 @@ class OfficialWiderFaceEvaluator:
                                         overlap_width_ratio=cfg["overlap_ratio"], postprocess_type="NMS", postprocess_match_threshold=0.5,
                                         postprocess_class_agnostic=True, verbose=0)
             rows = [[*p.bbox.to_xywh(), p.score.value] for p in res.object_prediction_list]
-        else:
-            self.detection_model.perform_inference(img)
-            self.detection_model.convert_original_predictions(shift_amount=[0, 0], full_shape=list(img.shape[:2]))
-            rows = [[*p.bbox.to_xywh(), p.score.value] for p in self.detection_model.object_prediction_list]
-        return np.asarray(rows, np.float64).reshape(-1, 5) if rows else np.array([])
+            return np.asarray(rows, np.float64).reshape(-1, 5) if rows else np.array([])
+        # baseline (:219-243): the YOLO object itself at its default imgsz (640), float xyxy -> top-left x, y, w, h — not the wrapper's
+        # image_size, not the int-truncated boxes of convert_original_predictions
+        results = self.detection_model.model(img, conf=self.inference_confidence, verbose=False)
+        boxes = results[0].boxes
+        if len(boxes) == 0:
+            return np.array([])
+        xyxy = boxes.xyxy.cpu().numpy()
+        x1, y1 = xyxy[:, 0], xyxy[:, 1]
+        xywh = np.column_stack((x1, y1, xyxy[:, 2] - x1, xyxy[:, 3] - y1))
+        return np.column_stack((xywh, boxes.conf.cpu().numpy())).astype("float")
 
     def _run_inference_on_all_images(self):
         predictions = defaultdict(dict)

@@ -674,16 +674,31 @@ std::vector<JpegDecodeWs*> g_dec_free;
 }  // namespace
 
 JpegDecodeWs* jpeg_ws_acquire() {
+  int dev = 0;
+  FFP_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lock(g_dec_mu);
-  if (g_dec_free.empty()) return new JpegDecodeWs();
-  JpegDecodeWs* w = g_dec_free.back();
-  g_dec_free.pop_back();
+  for (size_t i = 0; i < g_dec_free.size(); ++i)
+    if (g_dec_free[i]->device == dev) {               // a workspace's buffers live on the device that was current when it was made
+      JpegDecodeWs* w = g_dec_free[i];
+      g_dec_free.erase(g_dec_free.begin() + i);
+      return w;
+    }
+  JpegDecodeWs* w = new JpegDecodeWs();
+  w->device = dev;
   return w;
 }
 
 void jpeg_ws_release(JpegDecodeWs* ws) {
-  std::lock_guard<std::mutex> lock(g_dec_mu);
-  g_dec_free.push_back(ws);                          // (kept for the life of the process: a handful of frames' worth of staging)
+  constexpr size_t kPoolCap = 32;                     // a handful of frames' worth of staging per device; beyond that, free
+  std::unique_lock<std::mutex> lock(g_dec_mu);
+  if (g_dec_free.size() < kPoolCap) { g_dec_free.push_back(ws); return; }
+  lock.unlock();
+  int cur = 0;
+  const int owner = ws->device;
+  (void)hipGetDevice(&cur);
+  if (cur != owner) (void)hipSetDevice(owner);
+  delete ws;
+  if (cur != owner) (void)hipSetDevice(cur);
 }
 
 void jpeg_reconstruct_device(const JpegScan& s, JpegDecodeWs& ws, unsigned char* d_out, long long stride, int bgr, hipStream_t st) {

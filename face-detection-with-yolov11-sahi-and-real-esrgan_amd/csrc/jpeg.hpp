@@ -32,6 +32,7 @@ struct JpegDecodeWs {
   HostPinned host[3];
   DevBuf dev[3], plane[3], qt;
   size_t cap[3] = {0, 0, 0};
+  int device = 0;                               // the pool hands a workspace out only on the device it was made on
   void ensure(const JpegScan& s);               // sizes everything for the scan and points s.coef at the pinned planes
 };
 JpegDecodeWs* jpeg_ws_acquire();

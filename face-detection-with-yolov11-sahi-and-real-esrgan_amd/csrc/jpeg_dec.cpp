@@ -27,12 +27,16 @@ struct HuffTab {
     for (int l = 1; l <= 16; ++l) {
       valptr[l] = k;
       mincode[l] = code;
+      FFP_CHECK(code + bits[l - 1] <= (1 << l), FFP_ERR_ARG, "jpeg: bad Huffman table (over-subscribed at length %d)", l);
       for (int i = 0; i < bits[l - 1]; ++i, ++k, ++code) {
         if (l <= 9) {
           const int lo = code << (9 - l);
           for (int f = 0; f < (1 << (9 - l)); ++f) { look_len[lo + f] = (unsigned char)l; look_sym[lo + f] = v[k]; }
         }
       }
+      // a length-l code must fit in l bits and must not be all ones (jdhuff.c: JERR_BAD_HUFF_TABLE); this also keeps
+      // lo + f < 512 above: an over-subscribed table is rejected before it can index past the lookup arrays
+      FFP_CHECK(code < (1 << l), FFP_ERR_ARG, "jpeg: bad Huffman table (codes of length %d do not fit)", l);
       maxcode[l] = bits[l - 1] ? code - 1 : -1;
       code <<= 1;
     }
@@ -97,11 +101,13 @@ void jpeg_entropy_decode(const unsigned char* d, long long n, JpegScan& out, boo
   bool have_qt[4] = {false, false, false, false};
   int comp_id[3] = {0, 0, 0};
   int dri = 0;
+  int adobe_transform = -1;
   long long i = 2;
   bool sof = false;
   while (true) {
     FFP_CHECK(i + 4 <= n && d[i] == 0xFF, FFP_ERR_ARG, "jpeg: marker expected at byte %lld", i);
-    while (i + 1 < n && d[i + 1] == 0xFF) ++i;
+    while (i + 1 < n && d[i + 1] == 0xFF) ++i;              // fill bytes
+    FFP_CHECK(i + 4 <= n, FFP_ERR_ARG, "jpeg: truncated marker at byte %lld", i);
     const int m = d[i + 1];
     const int L = (d[i + 2] << 8) | d[i + 3];
     FFP_CHECK(L >= 2 && i + 2 + L <= n, FFP_ERR_ARG, "jpeg: truncated segment");
@@ -144,11 +150,16 @@ void jpeg_entropy_decode(const unsigned char* d, long long n, JpegScan& out, boo
       sof = true;
     } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xC7) || (m >= 0xC9 && m <= 0xCB) || (m >= 0xCD && m <= 0xCF)) {
       fail(FFP_ERR_ARG, "jpeg: progressive / lossless / arithmetic-coded files are not supported (marker 0x%02X)", m);
+    } else if (m == 0xEE) {
+      // Adobe APP14: transform 0 on a 3-component file means the samples are RGB, not YCbCr (jdapimin.c default_decompress_parms)
+      if (sl >= 12 && std::memcmp(s, "Adobe", 5) == 0) adobe_transform = s[11];
     } else if (m == 0xDD) {
       FFP_CHECK(sl >= 2, FFP_ERR_ARG, "jpeg: bad DRI");
       dri = (s[0] << 8) | s[1];
     } else if (m == 0xDA) {
       FFP_CHECK(sof, FFP_ERR_ARG, "jpeg: scan before frame header");
+      FFP_CHECK(!(out.ncomp == 3 && (adobe_transform == 0 || (comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B'))), FFP_ERR_ARG,
+                "jpeg: RGB-coded files (Adobe transform 0 / component ids R,G,B) are not supported");
       FFP_CHECK(sl >= 1 && s[0] == out.ncomp && sl >= 4 + 2 * out.ncomp, FFP_ERR_ARG, "jpeg: non-interleaved scans are not supported");
       for (int c = 0; c < out.ncomp; ++c) {
         int ci = -1;

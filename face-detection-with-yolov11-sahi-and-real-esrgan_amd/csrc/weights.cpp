@@ -39,6 +39,7 @@ void WeightFile::parse(const void* bytes, size_t n) {
     // no sum of file-provided 64-bit fields: each is checked against what is left, so nothing can wrap
     FFP_CHECK(off <= n - data_off && nb <= n - data_off - off && nb / 4 == ht.numel() && nb % 4 == 0, FFP_ERR_WEIGHTS,
               "FFPW: tensor %s out of bounds", name.c_str());
+    FFP_CHECK(reinterpret_cast<uintptr_t>(base + data_off + off) % alignof(float) == 0, FFP_ERR_WEIGHTS, "FFPW: tensor %s is not 4-byte aligned", name.c_str());
     ht.data = reinterpret_cast<const float*>(base + data_off + off);
     t[name] = ht;
   }

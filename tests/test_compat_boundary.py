@@ -168,3 +168,78 @@ def test_presentation_helpers_write_the_reference_outputs(shims, tmp_path):
     empty = PredictionResult(object_prediction_list=[], image=path, durations_in_seconds={})
     create_detection_summary(empty, path, 0.5, s, 160, 120, 640, 640)
     assert "Tidak ada wajah yang terdeteksi." in open(s, encoding="utf-8").read()
+
+
+def test_cv2_shim_imread_applies_exif_orientation(shims, tmp_path):
+    """`cv2.imread` rotates / mirrors by the EXIF orientation tag unless told not to; the shim does the same on both of its paths
+    (phone photographs came back in sensor orientation)."""
+    from PIL import Image
+    import cv2
+    if not hasattr(cv2, "_oriented"):
+        pytest.skip("a real OpenCV is installed")
+    rng = np.random.default_rng(11)
+    rgb = rng.integers(0, 255, (24, 40, 3)).astype(np.uint8)
+    for o in range(1, 9):
+        p = str(tmp_path / f"o{o}.png")
+        ex = Image.Exif()
+        ex[0x0112] = o
+        Image.fromarray(rgb).save(p, exif=ex)
+        from PIL import ImageOps
+        want = np.asarray(ImageOps.exif_transpose(Image.open(p)).convert("RGB"))[..., ::-1]
+        got = cv2.imread(p)
+        assert got.shape == want.shape and np.array_equal(got, want), o
+        assert cv2.imread(p, cv2.IMREAD_UNCHANGED).shape == rgb.shape
+
+
+def test_official_evaluator_hands_the_detector_what_the_reference_does(shims, tmp_path, monkeypatch):
+    """eval/eval_official_widerface.py:166-243: the image is read with cv2.imread (BGR) and, without SAHI, goes to the YOLO object
+    itself — `self.detection_model.model(img, conf=0.01, verbose=False)`, Ultralytics' default imgsz — whose FLOAT xyxy boxes become
+    top-left x, y, w, h; with SAHI it goes to get_sliced_prediction as the same BGR array."""
+    from PIL import Image
+    from eval.eval_official_widerface import OfficialWiderFaceEvaluator
+    import torch
+    rgb = np.zeros((48, 64, 3), np.uint8)
+    rgb[..., 0] = 200                                                  # a red picture: BGR has it in channel 2
+    p = str(tmp_path / "red.png")
+    Image.fromarray(rgb).save(p)
+    ev = OfficialWiderFaceEvaluator.__new__(OfficialWiderFaceEvaluator)
+    ev.use_sahi, ev.inference_confidence = False, 0.01
+    ev.sahi_config = {"slice_height": 640, "slice_width": 640, "overlap_ratio": 0.2}
+    seen = {}
+
+    class _B:
+        xyxy = torch.tensor([[1.25, 2.5, 11.75, 22.0]])
+        conf = torch.tensor([0.625])
+        def __len__(self):
+            return 1
+
+    class _R:
+        boxes = _B()
+
+    class _Yolo:
+        def __call__(self, img, **kw):
+            seen["img"], seen["kw"] = img, kw
+            return [_R()]
+
+    class _DM:
+        model = _Yolo()
+
+    ev.detection_model = _DM()
+    out = ev._run_single_inference(p)
+    assert seen["img"].shape == (48, 64, 3) and seen["img"][0, 0].tolist() == [0, 0, 200]          # BGR
+    assert seen["kw"] == {"conf": 0.01, "verbose": False}                                           # no imgsz: the YOLO default
+    assert out.dtype == np.float64 and np.allclose(out, [[1.25, 2.5, 10.5, 19.5, 0.625]])
+    assert ev._run_single_inference(str(tmp_path / "missing.jpg")).size == 0
+    # SAHI branch: same array, the reference's fixed arguments
+    import sahi.predict as sp
+    def fake_gsp(image, model, **kw):
+        seen["sahi_img"], seen["sahi_kw"] = image, kw
+        class _Res:
+            object_prediction_list = []
+        return _Res()
+    monkeypatch.setattr(sp, "get_sliced_prediction", fake_gsp)
+    ev.use_sahi = True
+    assert ev._run_single_inference(p).size == 0
+    assert seen["sahi_img"][0, 0].tolist() == [0, 0, 200]
+    assert seen["sahi_kw"] == dict(slice_height=640, slice_width=640, overlap_height_ratio=0.2, overlap_width_ratio=0.2, postprocess_type="NMS",
+                                   postprocess_match_threshold=0.5, postprocess_class_agnostic=True, verbose=0)
