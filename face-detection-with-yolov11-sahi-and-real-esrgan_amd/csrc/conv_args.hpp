@@ -119,4 +119,11 @@ void launch_conv_pw(ConvArgs& a, int shape, hipStream_t st);
 void conv_pw_init();
 bool conv_pw_enabled();         // FFP_PW=0 keeps the tuner to the generic shapes (A/B aid)
 
+// 3x3 fp32-split convs, stride 1 and 2, weights straight from L2 into MFMA operand registers (conv_k3d.hip): bit s of the mask =
+// force_shape s (17..21) can run this op; results are bit-identical to the generic kernel's
+unsigned conv_k3d_mask(const ConvOp& op, const ConvArgs& a);
+void launch_conv_k3d(ConvArgs& a, int shape, int stride, Level* out_lvl, hipStream_t st);
+void conv_k3d_init();
+bool conv_k3d_enabled();        // FFP_K3D=0 keeps the tuner to the generic shapes (A/B aid)
+
 }  // namespace ffp

@@ -962,6 +962,7 @@ void conv_kernels_init() {
   conv_rows_init();
   conv_rows16_init();
   conv_pw_init();
+  conv_k3d_init();
   Family<float, 1, 1>::init(); Family<float, 3, 1>::init(); Family<float, 3, 2>::init();
   Family<_Float16, 1, 1>::init(); Family<_Float16, 3, 1>::init(); Family<_Float16, 3, 2>::init();
   Family<X3, 1, 1>::init(); Family<X3, 3, 1>::init(); Family<X3, 3, 2>::init();
@@ -1066,6 +1067,12 @@ void launch_conv(const ConvOp& op, hipStream_t st) {
     FFP_HIP(hipGetLastError());
     return;
   }
+  if (a.force_shape >= 17 && a.force_shape <= 21) {      // direct-weight 3x3 kernels (conv_k3d.hip): picked by measurement (conv_tune) or by hand
+    FFP_CHECK(conv_k3d_mask(op, a) & (1u << a.force_shape), FFP_ERR_ARG, "conv %s: k3d shape %d cannot run this op", pc.name.c_str(), a.force_shape);
+    launch_conv_k3d(a, a.force_shape, op.stride, op.out.lvl, st);
+    FFP_HIP(hipGetLastError());
+    return;
+  }
   if (pc.dt == F16) launch_t<_Float16>(a, pc.k, op.stride, op.out.lvl, st);
   else if (pc.split) launch_t<X3>(a, pc.k, op.stride, op.out.lvl, st);
   else launch_t<float>(a, pc.k, op.stride, op.out.lvl, st);
@@ -1078,7 +1085,7 @@ int conv_tune(const ConvOp& op, hipStream_t st) {
   const ConvArgs a = make_conv_args(op);
   if (use_rows16(op, a) || conv_rows_eligible(op, a)) return -1;
   const unsigned mask = (pc.dt == F16 ? valid_t<_Float16>(a, pc.k, op.stride) : pc.split ? valid_t<X3>(a, pc.k, op.stride) : valid_t<float>(a, pc.k, op.stride)) |
-                        (conv_pw_enabled() ? conv_pw_mask(op, a) : 0u);
+                        (conv_pw_enabled() ? conv_pw_mask(op, a) : 0u) | (conv_k3d_enabled() ? conv_k3d_mask(op, a) : 0u);
   if (__builtin_popcount(mask) < 2) return -1;
   const int heur = pc.dt == F16 ? choose_t<_Float16>(a, pc.k, op.stride, op.out.lvl)
                    : pc.split ? choose_t<X3>(a, pc.k, op.stride, op.out.lvl) : choose_t<float>(a, pc.k, op.stride, op.out.lvl);
@@ -1098,7 +1105,7 @@ int conv_tune(const ConvOp& op, hipStream_t st) {
   };
   float best_t = 0.f, heur_t = 0.f;
   int best = -1;
-  for (int shape = 0; shape < 17; ++shape) {
+  for (int shape = 0; shape < 22; ++shape) {
     if (!(mask & (1u << shape))) continue;
     const float t1 = time_shape(shape, 2);                              // also builds the shape's tile table
     const int iters = std::min(24, std::max(3, (int)(300.f / std::max(t1, 1.f))));
@@ -1122,6 +1129,12 @@ std::string conv_variant(const ConvOp& op) {
   if (op.force_shape >= 10 && op.force_shape <= 16) {
     static const char* pw[7] = {"f32x3_k1s1_pw1x4", "f32x3_k1s1_pw2x2", "f32x3_k1s1_pw2x1", "f32x3_k1s1_pw1x4w", "f32x3_k1s1_pw2x2w", "f32x3_k1s1_pw2x1w", "f32x3_k1s1_pw1x4s"};
     return pw[op.force_shape - 10];
+  }
+  if (op.force_shape >= 17 && op.force_shape <= 21) {
+    static const char* k3[5] = {"d128", "d64", "d32", "d128x256", "d64x256"};
+    char b[64];
+    snprintf(b, sizeof(b), "f32x3_k3s%d_%s", op.stride, k3[op.force_shape - 17]);
+    return b;
   }
   const int shape = (op.force_shape >= 0 && op.force_shape < 6) ? op.force_shape
                     : pc.dt == F16 ? choose_t<_Float16>(a, pc.k, op.stride, op.out.lvl)

@@ -295,3 +295,55 @@ def test_conv1x1_over_virtual_upsample_concat(gpu_lib, case):
     finally:
         gpu_lib.op_conv2d_shape(-1)
     assert len(ran) >= 2, ran
+
+
+# conv_k3d.hip: force_shape -> minimum number of 32-channel output tiles
+K3D_SHAPES = {17: 3, 18: 2, 19: 1, 20: 3, 21: 2}
+K3D_CASES = [
+    # (n, h, w, cin, cout, stride, act, res)
+    (2, 32, 32, 32, 64, 1, 1, True),
+    (1, 18, 37, 64, 32, 1, 1, False),      # ragged tile edges in both directions
+    (1, 13, 11, 192, 64, 1, 0, True),
+    (2, 8, 8, 16, 16, 1, 1, True),         # one 16-channel chunk, cout below one tile
+    (1, 1, 1, 64, 32, 1, 1, False),        # a one-pixel image: everything but the centre tap reads padding
+    (1, 64, 48, 64, 128, 2, 1, False),
+    (1, 16, 16, 256, 256, 2, 1, False),
+    (3, 33, 31, 32, 64, 2, 1, False),      # odd sizes at stride 2
+    (1, 20, 20, 64, 128, 1, 1, False),
+    (1, 16, 24, 128, 96, 1, 0, True),      # 3 tiles: the 128-channel workgroup has an idle tile slot
+    (5, 64, 64, 128, 128, 2, 1, False),    # model.3-like: many tiles per persistent workgroup, 8 chunks per item
+    (7, 40, 24, 16, 32, 1, 1, True),       # model.2.m.0.cv2-like: one chunk per item (the stream changes item at every chunk)
+    (4, 16, 16, 128, 128, 1, 1, True),     # C3k bottleneck at 16 x 16
+    (2, 17, 16, 512, 64, 1, 1, False),     # 32 chunks
+    (61, 16, 16, 48, 160, 2, 1, False),    # more images than workgroup slots want; 5 tiles (two channel blocks of 128)
+]
+
+
+@pytest.mark.parametrize("case", K3D_CASES, ids=lambda c: "n%d_%dx%d_c%d-%d_s%d_a%d_r%d" % c)
+def test_conv_k3_direct_weight_kernels(gpu_lib, case):
+    """conv_k3d.hip (3x3 split-arithmetic convs, weights straight from L2 into MFMA operand registers, persistent tile walk): every
+    workgroup shape that can run the case, against the fp32 reference at the generic split kernel's tolerance AND bit for bit
+    against the generic kernel (same instruction, same fragments, same k order)."""
+    n, h, w, cin, cout, stride, act, has_res = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rng.standard_normal(cout, dtype=np.float32) * 0.1
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    res = rng.standard_normal((n, ho, wo, cout), dtype=np.float32) if has_res else None
+    kw = dict(stride=stride, act=act, res=res, res_scale=0.2 if has_res else 1.0, precision=gpu_lib.PREC_F32X3)
+    ref = ref_conv(x, wt, b, stride, 1, act, 0, res, 0.2, False)
+    gen = gpu_lib.op_conv2d(x, wt, b, **kw)
+    ran = 0
+    try:
+        for shape, min_tiles in sorted(K3D_SHAPES.items()):
+            if -(-cout // 32) < min_tiles:
+                continue
+            gpu_lib.op_conv2d_shape(shape)
+            y = gpu_lib.op_conv2d(x, wt, b, **kw)
+            np.testing.assert_allclose(y, ref, rtol=3e-5, atol=3e-5, err_msg=f"shape {shape}")
+            assert np.array_equal(y, gen), f"shape {shape}: differs from the generic kernel in {int((y != gen).sum())} of {y.size} values, max {np.abs(y - gen).max()}"
+            ran += 1
+    finally:
+        gpu_lib.op_conv2d_shape(-1)
+    assert ran >= 1
