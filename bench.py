@@ -110,7 +110,8 @@ def cpu_baseline(args, det_w, sr_w, frame, crop_boxes, premerge_rows):
     t_frame = t_slices + t_full + t_merge + t_sr_frame
     what = "bounded sample scaled to one frame" if args.cpu_sample else "one whole frame"
     return {"value": 1.0 / t_frame, "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"{what}: {len(idx)} of {len(boxes)} slices + full-frame pass + merge of {len(dets)} boxes + SR on {sr_sample} "
+            "sample": f"{what} (frame 0 of the timed loop, the crop boxes the GPU enhanced for it; one frame, not three: a frame costs ~70 s): "
+                      f"{len(idx)} of {len(boxes)} slices + full-frame pass + merge of {len(dets)} boxes + SR on {sr_sample} "
                       f"({t_frame:.1f} s/frame: det {t_slices + t_full:.1f}, merge {t_merge:.3f}, sr {t_sr_frame:.1f})"}
 
 
@@ -118,7 +119,7 @@ class Runner:
     """One configuration of the hot path: its pipeline, its resident plans, its timed loop."""
 
     def __init__(self, args, ctx, *, det_precision=None, imgsz=None, pp_type=None, class_agnostic=None, sr_sizes=None, frames_per_step=None,
-                 exchange=None, resident=None, pipe=None, det_batch=None, jpeg_io=False):
+                 exchange=None, resident=None, pipe=None, det_batch=None, sr_batch=None, jpeg_io=False):
         import torch
         from ffp_amd import _lib, pipeline, synth
         self.torch, self.pipeline, self.ctx, self.args = torch, pipeline, ctx, args
@@ -130,10 +131,22 @@ class Runner:
         self.sr_sizes = sr_sizes or args.sr_sizes
         self.B = frames_per_step or args.frames_per_step or self.world
         self.exchange = exchange or args.exchange
+        # how the frames of a step map to ranks (FramePipeline.layout): "local" = weak scaling, every rank runs its own frame by itself
+        # and holds nothing of the others'; "spread" = the north_star split, EVERY frame's items over all ranks, one all-gather per
+        # detection group (strong scaling); "global" = one contiguous split of all items (forced-exchange comparison row)
+        if self.world == 1:
+            self.mode = "local"
+        elif self.B == 1:
+            self.mode = "spread"
+        elif self.B == self.world and self.exchange == "auto":
+            self.mode = "local"
+        else:
+            self.mode = "global"
+        self.Bl = self.B if self.mode == "global" else 1          # frames of one step in THIS rank's super-frame
         self.resident = args.resident if resident is None else resident
         self.H, self.W = args.height, args.width
         self.DB = max(1, det_batch or args.det_batch_frames)
-        self.SB = max(1, args.sr_batch_frames)
+        self.SB = max(1, sr_batch or args.sr_batch_frames)
         self.cfg = pipeline.PipeConfig(slice_h=args.slice, slice_w=args.slice, overlap=args.overlap, imgsz=self.imgsz, conf=args.conf,
                                        pp_type=self.pp_type, class_agnostic=self.class_agnostic, sr_crops=args.sr_crops)
         if pipe is not None and pipe.det.precision == {"f16": _lib.PREC_F16, "f32x3": _lib.PREC_F32X3, "f32": _lib.PREC_F32}[self.det_precision]:
@@ -162,19 +175,32 @@ class Runner:
         # frame slots: a ring deep enough that a slot is never refilled while queued crops (held until SB frames are together) or the
         # SR batch in flight (whose crop gather reads the frames asynchronously on the enhancer's stream, include/ffp.h: d_frame stays
         # untouched until ffp_sr_wait) still read it; upload() also waits for the batch in flight if it ever meets its slot
-        self.nslots = -(-self.SB // (self.DB * self.B)) + 3
+        self.nslots = -(-self.SB // self.DB) + 3
         self.host_supers, self.slots = {}, {}
         self.state, self.pending, self.queue, self.group = {}, {}, [], {}
         self.sr_px = 0
+        self.tm = {}                                   # host-side wall time per stage over the timed loop (seconds)
+        self.lat_t0, self.lat = {}, []                 # per-frame latency: handed to the pipeline -> enhanced crops on the host
 
     # ---- frames: pinned host super-frames, three device slots per super-frame size, uploads on a copy stream ----------------
+    def frame_of(self, variant, f):
+        """Which synthetic frame sits at position f of a super-frame (ranks of a weak-scaling run take different ones)."""
+        hf = self.ctx["host_frames"]
+        return (variant + f + (self.rank if self.mode == "local" else 0)) % len(hf)
+
     def host_super(self, nf, variant):
+        """Pinned host super-frame of THIS rank's frames only (weak scaling: a rank never holds another rank's frames)."""
         key = (nf, variant)
         if key not in self.host_supers:
             hf = self.ctx["host_frames"]
-            sf = np.concatenate([hf[(variant + f) % len(hf)] for f in range(nf)], 0)
+            sf = np.concatenate([hf[self.frame_of(variant, f)] for f in range(nf)], 0)
             self.host_supers[key] = self.torch.from_numpy(sf).pin_memory()
         return self.host_supers[key]
+
+    def tick(self, name, t0):
+        t1 = time.perf_counter()
+        self.tm[name] = self.tm.get(name, 0.0) + (t1 - t0)
+        return t1
 
     def upload(self, gi, nf):
         """Start the host->device copy of group gi's super-frame (only the rows this rank reads) on the copy stream."""
@@ -188,7 +214,7 @@ class Runner:
                 torch.cuda.synchronize(self.dev)
             return self.slots[key], None
         key = (nf, gi % self.nslots)
-        if any(k == key for k, _, _ in self.queue):
+        if any(x[0] == key for x in self.queue):
             raise RuntimeError("frame slot ring too small: a slot with queued crops would be overwritten")
         if key in self.pending.get("slots", ()):
             self.drain_sr()                            # the SR batch in flight still gathers crops from this slot
@@ -199,9 +225,9 @@ class Runner:
         if self.jpeg_io:
             slot, hf = self.slots[key], self.ctx["host_frames"]
             fb = self.H * self.W * 3
-            futs = [self.pool.submit(self._lib.jpeg_decode_dev, self.jpegs[(variant + f) % len(hf)], slot.data_ptr() + f * fb, self.W * 3, fb, False, self.ctx["local_rank"])
+            futs = [self.pool.submit(self._lib.jpeg_decode_dev, self.jpegs[self.frame_of(variant, f)], slot.data_ptr() + f * fb, self.W * 3, fb, False, self.ctx["local_rank"])
                     for f in range(nf)]
-            self.jpeg_bytes_in += sum(len(self.jpegs[(variant + f) % len(hf)]) for f in range(nf))
+            self.jpeg_bytes_in += sum(len(self.jpegs[self.frame_of(variant, f)]) for f in range(nf))
             self.frames_in = getattr(self, "frames_in", 0) + nf
 
             class _Wait:
@@ -211,7 +237,7 @@ class Runner:
             self.state["upload_bytes"] = 0
             return slot, _Wait()
         slot, src = self.slots[key], self.host_super(nf, variant)
-        r0, r1 = self.pipe.layout(self.H, self.W, nf).rows_needed(self.rank, self.H)
+        r0, r1 = self.pipe.layout(self.H, self.W, nf, self.mode).rows_needed(0 if self.mode == "local" else self.rank, self.H)
         ev = torch.cuda.Event()
         if r1 > r0:
             with torch.cuda.stream(self.copy_stream):
@@ -234,9 +260,11 @@ class Runner:
 
     def drain_sr(self):
         if self.pending:
+            t0 = time.perf_counter()
             self.pipe.wait_sr()
             out = self.pending.pop("out")
             self.pending.pop("slots", None)
+            ids = self.pending.pop("frame_ids", ())
             if self.jpeg_io:
                 offs, hs, ws = self.pending.pop("meta")
                 files = self._lib.jpeg_encode_batch_dev(out.data_ptr(), offs, hs, ws, 95, bgr=True, device=self.ctx["local_rank"])     # enhanced crops -> .jpg bytes on the host
@@ -245,19 +273,31 @@ class Runner:
             if self.host_sr is None or self.host_sr.numel() < out.numel():
                 self.host_sr = self.torch.empty((int(out.numel() * 1.5),), dtype=self.torch.uint8).pin_memory()
             self.host_sr[:out.numel()].copy_(out)                  # enhanced crops -> host
+            t1 = self.tick("sr_wait_and_d2h", t0)
+            for fid in ids:
+                if fid in self.lat_t0:
+                    self.lat.append(t1 - self.lat_t0.pop(fid))
 
     def flush_sr(self, slot):
         if not self.queue:
             return
         self.drain_sr()
-        q = [x[1:] for x in self.queue if len(x[2])]
+        q = [x[1:3] for x in self.queue if len(x[2])]
         keys = {x[0] for x in self.queue if len(x[2])}
+        ids = [x[3] for x in self.queue]
         self.queue.clear()
         if not q:
+            t1 = time.perf_counter()
+            for fid in ids:                            # frames without crops are done once their detections are on the host
+                if fid in self.lat_t0:
+                    self.lat.append(t1 - self.lat_t0.pop(fid))
             return
+        t0 = time.perf_counter()
         out, offs = self.pipe.enhance_crops_multi([x[0] for x in q], self.H, self.W, [x[1] for x in q], slot=slot)
+        self.tick("sr_submit", t0)
         self.pending["out"] = out
         self.pending["slots"] = keys
+        self.pending["frame_ids"] = ids
         if self.jpeg_io:
             bx = np.concatenate([x[1] for x in q], 0).astype(np.int64)
             bx = np.stack([np.clip(bx[:, 0], 0, self.W), np.clip(bx[:, 1], 0, self.H), np.clip(bx[:, 2], 0, self.W), np.clip(bx[:, 3], 0, self.H)], 1)   # as the library clamps
@@ -274,42 +314,58 @@ class Runner:
         """Detect the group's frames as one ragged batch (detector stream) while the next group's frames upload (copy stream) and the
         previous frames' crops are enhanced (enhancer stream); then merge every frame and queue its crops."""
         torch, pipe, a = self.torch, self.pipe, self.args
-        B, H, W = self.B, self.H, self.W
+        B, Bl, H, W = self.B, self.Bl, self.H, self.W
         sf, ev = self.group.pop("next")
         slot_key = self.group.pop("next_key")
         if nxt is not None:
-            self.group["next"] = self.upload(gi + 1, B * nxt[1])          # overlaps this group's detection
+            self.group["next"] = self.upload(gi + 1, Bl * nxt[1])         # overlaps this group's detection
             self.group["next_key"] = self.state["slot_key"]
+        t0 = time.perf_counter()
         if ev is not None:
             ev.synchronize()
+        t0 = self.tick("upload_wait", t0)
+        for i in range(g0, g0 + gsz):
+            for fb in range(Bl):
+                self.lat_t0[(i, fb)] = t0
         if profile:
             pipe.det.set_profile(True)
-        dets, counts, L, gathered = pipe.detect(sf, H, W, B * gsz, exchange=self.exchange)
+        dets, counts, L, gathered = pipe.detect(sf, H, W, Bl * gsz, exchange=self.exchange, mode=self.mode)
         if profile:
             pipe.det.set_profile(False)
+        self.tm["detect"] = self.tm.get("detect", 0.0) + pipe.t_detect
+        self.tm["exchange"] = self.tm.get("exchange", 0.0) + pipe.t_exchange
         self.state["gathered"] = gathered
+        my = 0 if self.mode == "local" else self.rank
         for i in range(g0, g0 + gsz):
             last = profile and i == n_total - 1
-            for fb in range(B):
-                f = (i - g0) * B + fb
+            for fb in range(Bl):
+                f = (i - g0) * Bl + fb
                 spread = L.owner(f) < 0                                                   # this frame's items live on several ranks
-                if not spread and L.owner(f) != self.rank:
+                if not spread and L.owner(f) != my:
+                    self.lat_t0.pop((i, fb), None)
                     continue
                 if spread and not gathered:
                     raise RuntimeError("frame items are spread over ranks but the exchange was disabled")
+                t0 = time.perf_counter()
                 rows_d, n_d = pipe.merge_frame_of(dets, counts, L, f, gathered)      # replicated on every rank when spread (§8e)
                 n = pipe.merged_count(n_d)
                 self.host_rows[:n].copy_(rows_d[:n])                                   # merged detections -> host
                 rows = self.host_rows[:n].numpy().copy()
+                self.tick("merge_and_d2h", t0)
                 rows[:, [1, 3]] -= f * H
                 self.state["rows"] = rows
                 if a.sr_crops > 0:
-                    boxes = self.crop_boxes(rows, i * B + fb)
+                    seed = i * B + (self.rank if self.mode == "local" else fb)
+                    boxes = self.crop_boxes(rows, seed)
                     self.state["boxes"] = boxes
+                    if seed == 0:
+                        self.state["boxes_frame0"] = boxes                              # what the CPU baseline enhances
                     if spread:                                                          # crops of ONE frame over the ranks: LPT by area
                         own = self.pipeline.lpt_assign((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]), self.world) == self.rank
                         boxes = boxes[own]
-                    self.queue.append((slot_key, sf[f * H:(f + 1) * H], boxes))
+                    self.queue.append((slot_key, sf[f * H:(f + 1) * H], boxes, (i, fb)))
+                else:
+                    self.lat.append(time.perf_counter() - self.lat_t0.pop((i, fb)))
             if a.sr_crops > 0 and (len(self.queue) >= self.SB or last):
                 prof = self.prof_flush is not None and self.flush_no == self.prof_flush     # the kernel times of ONE whole SR batch
                 if prof:
@@ -329,11 +385,11 @@ class Runner:
         if not gs:                                     # --warmup 0
             return
         # SR kernels are profiled on the last FULL batch of the loop (a trailing partial batch would understate the launch sizes)
-        n_flush = -(-(n_steps * self.B) // self.SB) if self.args.sr_crops > 0 else 0
-        n_full = (n_steps * self.B) // self.SB
+        n_flush = -(-(n_steps * self.Bl) // self.SB) if self.args.sr_crops > 0 else 0
+        n_full = (n_steps * self.Bl) // self.SB
         self.prof_flush = (max(n_full, 1) - 1 if n_flush else None) if profile_last else None
         self.flush_no = 0
-        self.group["next"] = self.upload(0, self.B * gs[0][1])
+        self.group["next"] = self.upload(0, self.Bl * gs[0][1])
         self.group["next_key"] = self.state["slot_key"]
         for gi, (g0, gsz) in enumerate(gs):
             self.run_group(gi, g0, gsz, n_steps, gs[gi + 1] if gi + 1 < len(gs) else None, profile_last and gi == len(gs) - 1)
@@ -351,11 +407,11 @@ class Runner:
         """Untimed, like loading weights: lay out, tune and graph-capture the detector plan of every group size, and the enhancer plan of
         every capacity bucket the loops will meet (a plan is keyed by capacity, not by crop sizes: a stream builds each bucket once)."""
         for gsz in sorted({g[1] for n in (warmup, steps) for g in self.groups(n)}):
-            sf, ev = self.upload(0, self.B * gsz)
+            sf, ev = self.upload(0, self.Bl * gsz)
             if ev is not None:
                 ev.synchronize()
             for _ in range(3):
-                self.pipe.detect(sf, self.H, self.W, self.B * gsz, exchange=self.exchange)
+                self.pipe.detect(sf, self.H, self.W, self.Bl * gsz, exchange=self.exchange, mode=self.mode)
         self.loop(max(warmup, 2 * self.DB))
         if self.args.sr_crops > 0:
             self.loop(steps)                           # rehearsal with the timed loop's own crop sizes: every bucket it meets exists afterwards
@@ -367,6 +423,7 @@ class Runner:
         self.loop(warmup)
         self.barrier()
         self.sr_px = 0
+        self.tm, self.lat, self.lat_t0 = {}, [], {}
         t0 = time.perf_counter()
         self.loop(steps, profile_last=profile_last)
         self.barrier()
@@ -375,7 +432,21 @@ class Runner:
             t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev if self.ctx["backend"] == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        self.dt_own = time.perf_counter() - t0
         return dt
+
+    def report(self, steps):
+        """Per-rank view of the timed loop: host wall time per stage (ms per step), per-frame latency percentiles."""
+        lat = np.sort(np.asarray(self.lat, np.float64)) * 1e3
+        mine = {"rank": self.rank, "stage_ms_per_step": {k: round(v / max(steps, 1) * 1e3, 3) for k, v in sorted(self.tm.items())},
+                "frames": int(len(lat)), "latency_ms": ({"p50": round(float(lat[len(lat) // 2]), 2), "p99": round(float(lat[min(len(lat) - 1, int(len(lat) * 0.99))]), 2),
+                                                        "max": round(float(lat[-1]), 2)} if len(lat) else None)}
+        if self.world == 1:
+            return [mine]
+        import torch.distributed as dist
+        out = [None] * self.world
+        dist.all_gather_object(out, mine)
+        return out
 
     def describe(self):
         a = self.args
@@ -417,6 +488,7 @@ def main():
     dt = main_r.timed(args.warmup, args.steps)
     B = main_r.B
     fps = B * args.steps / dt
+    main_report = main_r.report(args.steps)
     pipe = main_r.pipe
     prof = [dict(p, stage="det") for p in pipe.det.profile()]
     if pipe.sr is not None:
@@ -439,24 +511,33 @@ def main():
             # reported in place of the row; the rows that follow still run
             r = None
             try:
+                steps_r = kw.pop("steps", ss)
                 r = Runner(args, ctx, pipe=pipe, **kw)
-                d = r.timed(sw, ss, profile_last=False)
-                secondary[name] = {"value": round(r.B * ss / d, 3), "unit": "frames/s", "ms_per_step": round(d / ss * 1e3, 3), "steps": ss, "workload": r.describe(),
-                                   "frames_per_step": r.B, "gathered": bool(r.state.get("gathered", False))}
+                d = r.timed(sw, steps_r, profile_last=False)
+                rep = r.report(steps_r)
+                secondary[name] = {"value": round(r.B * steps_r / d, 3), "unit": "frames/s", "ms_per_step": round(d / steps_r * 1e3, 3), "steps": steps_r, "workload": r.describe(),
+                                   "frames_per_step": r.B, "det_batch_frames": r.DB, "sr_batch_frames": r.SB, "mode": r.mode, "gathered": bool(r.state.get("gathered", False)),
+                                   "latency_ms_rank0": rep[0]["latency_ms"]}
+                if world > 1:
+                    secondary[name]["per_rank"] = rep
             except Exception as e:      # noqa: BLE001
                 secondary[name] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
                 print(f"[bench] secondary row {name} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
             return r
 
+        # the reference's own order: strictly one frame, one SR pass at a time (docs sahi/predict.py:226,270) — nothing batched across frames
+        sec("frame_by_frame", det_batch=1, sr_batch=1)
+        sec("steps_200", steps=200)                       # the headline configuration over a 10x longer timed region
         sec("frames_resident_in_hbm", resident=True)
         if args.sr_crops > 0 and args.sr_sizes != "fixed":
             sec("sr_sizes_fixed", sr_sizes="fixed")
         sec("merge_nms_ios_agnostic", pp_type="NMS", class_agnostic=True)
         if world > 1:
             if not main_state.get("gathered", False):
-                sec("with_allgather", exchange="always")
+                sec("with_allgather", exchange="always", det_batch=1)       # "global" layout: a rank's super-frame spans every rank's frame
             if main_r.B != 1:
-                r = sec("one_frame_across_ranks", frames_per_step=1, exchange="auto", det_batch=1)      # ONE frame's 61 items over the ranks
+                # the north_star split: EVERY frame's 61 items over the ranks, det_batch_frames frames in flight, one all-gather per group
+                r = sec("one_frame_across_ranks", frames_per_step=1, exchange="auto")
                 secondary["one_frame_across_ranks"]["scaling"] = "strong"        # (key exists whether or not the row failed)
         if args.sr_crops > 0 and world == 1:
             r = sec("with_jpeg_decode_and_encode", jpeg_io=True)
@@ -500,13 +581,17 @@ def main():
             "config": {"workload": main_r.describe(),
                        "span": ("frames resident in HBM -> results in host memory" if main_r.resident else
                                 "frame in pinned host memory -> upload (copy stream) -> detect -> merge -> SR -> detections + enhanced crops in host memory"),
-                       "frames_per_step": B, "det_batch_frames": main_r.DB, "sr_batch_frames": main_r.SB,
+                       "frames_per_step": B, "det_batch_frames": main_r.DB, "sr_batch_frames": main_r.SB, "mode": main_r.mode,
+                       "collective": {"backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None, "ranks": world,
+                                      "all_gathers_per_group": int(bool(main_state.get("gathered")))},
                        "parallelism": (f"items of {B} frame(s) in {world} contiguous cost-balanced blocks; "
                                        + ("one all-gather per group" if main_state.get("gathered") else "whole frames per rank: no exchange needed")) if world > 1 else "single GPU",
                        "upload_bytes_per_group_per_rank": int(main_state.get("upload_bytes", 0)),
                        "sr_px_per_frame_mean": round(main_sr_px * world / max(args.steps * B, 1), 1),
                        "detections_last_frame": int(main_state.get("rows", np.zeros((0, 1))).shape[0]),
                        "det_graph_status": det_graph, "sr_plan_state": sr_state},
+            "latency_ms_rank0": main_report[0]["latency_ms"],
+            "per_rank": main_report,
             "stage_ms_last_call": {k: round(v, 3) for k, v in stage_ms.items()},
             "sr_ms_last_call": round(sr_ms, 3) if sr_ms is not None else None,
             "conv_profile_last_step": [{"kernel": p["variant"], "stage": p["stage"], "ms": round(p["ms"], 3), "launches": p["launches"],
@@ -519,7 +604,7 @@ def main():
             sf, _ = base_r.upload(0, 1)
             d, c, _, _ = pipe.detect(sf, H, W, 1)
             pre = torch.cat([d[k, :int(c[k])] for k in range(d.shape[0])], 0).cpu().numpy()
-            boxes = main_state.get("boxes", np.zeros((0, 4), np.int32))
+            boxes = main_state.get("boxes_frame0", main_state.get("boxes", np.zeros((0, 4), np.int32)))      # the crops the GPU enhanced for THIS frame (frame 0 of the timed loop)
             res["cpu_baseline"] = cpu_baseline(args, ctx["det_w"], ctx["sr_w"], ctx["host_frames"][0], boxes, pre)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -85,6 +85,7 @@ _SIGS = {
     "ffp_sr_plan_state": (C.c_int, [C.c_void_p, _p(C.c_int32), _p(C.c_int32)]),
     "ffp_det_graph_status": (C.c_int, [C.c_void_p, _p(C.c_int32)]),
     "ffp_det_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),
+    "ffp_det_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ffp_sr_last_ms": (C.c_int, [C.c_void_p, _p(C.c_float)]),
     "ffp_sr_last_conv_stats": (C.c_int, [C.c_void_p, _p(C.c_double), _p(C.c_float), _p(C.c_int32)]),
     "ffp_sr_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
@@ -289,6 +290,10 @@ class Detector:
     def set_lanes(self, mode: int):
         """0 (default) one stream; 1 head towers and C3k side convs as parallel graph branches (detector-only deployments)."""
         _check(lib().ffp_det_set_lanes(self._h, int(mode)))
+
+    def stream_wait_event(self, hip_event: int):
+        """Order the handle's following work behind a hipEvent_t of this process (torch.cuda.Event.cuda_event)."""
+        _check(lib().ffp_det_stream_wait_event(self._h, C.c_void_p(int(hip_event))))
 
     def set_profile(self, on: bool):
         _check(lib().ffp_det_set_profile(self._h, int(on)))

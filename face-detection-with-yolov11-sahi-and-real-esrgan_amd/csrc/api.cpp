@@ -266,6 +266,14 @@ int ffp_det_set_lanes(ffp_det* d, int mode) {
   FFP_API_END
 }
 
+int ffp_det_stream_wait_event(ffp_det* d, void* hip_event) {
+  FFP_API_BEGIN
+  FFP_CHECK(d && hip_event, FFP_ERR_ARG, "det_stream_wait_event: null argument");
+  FFP_HIP(hipSetDevice(d->eng.device()));
+  FFP_HIP(hipStreamWaitEvent(d->eng.stream(), reinterpret_cast<hipEvent_t>(hip_event), 0));
+  FFP_API_END
+}
+
 int ffp_det_graph_status(ffp_det* d, int32_t* out_state) {
   FFP_API_BEGIN
   FFP_CHECK(d && out_state, FFP_ERR_ARG, "null argument");

@@ -115,28 +115,59 @@ def shard(n_items: int, rank: int, world: int):
 
 
 class Layout:
-    """Where every work item of a super-frame lives: global order `items`, per-rank contiguous blocks `bounds`, and the slot
-    of an item in the fixed-cap exchange buffer (rank r's k-th item sits at r * per + k; unused slots keep count 0, so any
-    slot range is still in SAHI's order)."""
+    """Where every work item of a super-frame lives: global order `items`, per-rank shares, and the slot of an item in the fixed-cap
+    exchange buffer (unused slots keep count 0, so any slot range is still in SAHI's order).
 
-    def __init__(self, items: np.ndarray, n_frames: int, world: int, costs: np.ndarray):
+    Two partitions. Default: ONE contiguous cost-balanced split of the whole item list (rank r's k-th item sits at slot r * per + k);
+    with one frame per rank every frame lands on one rank and nothing has to be exchanged. `spread=True` (the north_star's split,
+    strong scaling): EVERY frame's items are cut into `world` contiguous cost-balanced blocks and rank r takes block r of every
+    frame, so a group of frames costs ONE all-gather; the gathered buffer, reordered frame-major ([frame][rank][per]), holds each
+    frame's items contiguously and in SAHI's order."""
+
+    def __init__(self, items: np.ndarray, n_frames: int, world: int, costs: np.ndarray, spread: bool = False):
         self.items, self.n_frames, self.world = items, n_frames, world
         self.ipf = len(items) // n_frames
-        self.bounds = partition(costs, world)
-        self.per = max(1, max(h - l for l, h in self.bounds))
+        self.spread = bool(spread) and world > 1
+        if self.spread:
+            self.frame_bounds = partition(costs[:self.ipf], world)           # frames of a group have the same items: one split serves all
+            self.per = max(1, max(h - l for l, h in self.frame_bounds))
+            self.bounds = None
+        else:
+            self.bounds = partition(costs, world)
+            self.per = max(1, max(h - l for l, h in self.bounds))
+
+    def local_items(self, rank: int) -> np.ndarray:
+        """This rank's items in the order it runs them (spread: block `rank` of frame 0, of frame 1, ...)."""
+        if self.spread:
+            lo, hi = self.frame_bounds[rank]
+            return np.concatenate([self.items[f * self.ipf + lo:f * self.ipf + hi] for f in range(self.n_frames)], 0).reshape(-1, 4)
+        lo, hi = self.bounds[rank]
+        return self.items[lo:hi]
+
+    def local_slots(self) -> int:
+        """Rows of a rank's fixed-cap exchange buffer."""
+        return self.n_frames * self.per if self.spread else self.per
 
     def rank_of(self, i: int) -> int:
-        for r, (lo, hi) in enumerate(self.bounds):
-            if lo <= i < hi:
+        b = self.frame_bounds if self.spread else self.bounds
+        j = i % self.ipf if self.spread else i
+        for r, (lo, hi) in enumerate(b):
+            if lo <= j < hi:
                 return r
         raise IndexError(i)
 
     def slot(self, i: int) -> int:
+        """Slot of item i in the gathered buffer (spread: after the frame-major reorder)."""
         r = self.rank_of(i)
+        if self.spread:
+            f, j = divmod(i, self.ipf)
+            return (f * self.world + r) * self.per + (j - self.frame_bounds[r][0])
         return r * self.per + (i - self.bounds[r][0])
 
     def owner(self, f: int) -> int:
         """The rank holding ALL items of frame f, or -1 when the frame is spread over ranks."""
+        if self.spread:
+            return -1
         a, b = f * self.ipf, (f + 1) * self.ipf
         r = self.rank_of(a)
         return r if self.bounds[r][1] >= b else -1
@@ -149,6 +180,9 @@ class Layout:
     def frame_slots(self, f: int, gathered: bool, rank: int = 0):
         """(first slot, slot count) of frame f in the gathered buffer, or in rank's local buffer when nothing was exchanged."""
         a, b = f * self.ipf, (f + 1) * self.ipf
+        if self.spread:
+            assert gathered, "a spread frame needs the exchange"
+            return f * self.world * self.per, self.world * self.per
         if gathered:
             s0, s1 = self.slot(a), self.slot(b - 1)
             return s0, s1 - s0 + 1
@@ -159,6 +193,8 @@ class Layout:
     def rows_needed(self, rank: int, H: int):
         """Row range of the super-frame rank must have resident: the rows its items read, the frames it owns (merge + crops) and
         every frame that is spread over ranks (its merge is replicated and its crops are placed on all ranks by LPT)."""
+        if self.spread:
+            return 0, self.n_frames * H
         lo, hi = self.bounds[rank]
         ys = [(int(self.items[i][1]), int(self.items[i][3])) for i in range(lo, hi)]
         ys += [(f * H, (f + 1) * H) for f in range(self.n_frames) if self.owner(f) in (rank, -1)]
@@ -226,6 +262,14 @@ def exchange_detections(local_dets, local_counts, world: int):
     return g, gc
 
 
+def frame_major(g, gc, world: int, n_frames: int, per: int):
+    """Gathered [rank][frame][per] -> [frame][rank][per]: every frame's slots contiguous and in SAHI's order (Layout spread=True)."""
+    tail = tuple(g.shape[1:])
+    g2 = g.view(world, n_frames, per, *tail).transpose(0, 1).contiguous().view(n_frames * world * per, *tail)
+    gc2 = gc.view(world, n_frames, per).transpose(0, 1).contiguous().view(n_frames * world * per)
+    return g2, gc2
+
+
 class FramePipeline:
     """One rank's share of the pipeline. `torch` is imported lazily: it provides device tensors and the collective."""
 
@@ -278,42 +322,65 @@ class FramePipeline:
             raise _lib.FfpError(1, f"{n} merged detections exceed merge_cap={self.cfg.merge_cap}: raise PipeConfig.merge_cap")
         return n
 
-    def layout(self, H: int, W: int, n_frames: int = 1) -> Layout:
-        key = (H, W, n_frames)
+    def layout(self, H: int, W: int, n_frames: int = 1, mode: str = "global") -> Layout:
+        """mode "global": one contiguous split of all items over the ranks; "spread": every frame's items over the ranks (one
+        all-gather per call); "local": this rank runs all n_frames frames by itself (weak scaling: nothing is shared)."""
+        key = (H, W, n_frames, mode)
         L = self._layouts.get(key)
         if L is None:
             items = frame_items(H, W, self.cfg, n_frames)
-            L = Layout(items, n_frames, self.world, item_costs(items, self.cfg.imgsz))
+            L = Layout(items, n_frames, 1 if mode == "local" else self.world, item_costs(items, self.cfg.imgsz), spread=(mode == "spread"))
             self._layouts[key] = L
         return L
 
-    def detect(self, d_frame, H: int, W: int, n_frames: int = 1, exchange: str = "auto"):
+    def detect(self, d_frame, H: int, W: int, n_frames: int = 1, exchange: str = "auto", mode: str = "global"):
         """d_frame: uint8 cuda tensor (n_frames*H, W, 3); only layout.rows_needed(rank) have to be valid.
         Returns (dets [slots][max_det][stride], counts [slots], layout, gathered). exchange: "auto" skips the all-gather when every
-        frame's items live on one rank (weak scaling with whole frames per rank), "always" / "never" force it."""
+        frame's items live on one rank (weak scaling with whole frames per rank), "always" / "never" force it. mode: see layout()."""
+        import time
         torch, cfg = self.torch, self.cfg
-        L = self.layout(H, W, n_frames)
-        lo, hi = L.bounds[self.rank]
-        local = self._buf("local_dets", (L.per, cfg.max_det, self.stride), torch.float32)
-        lcount = self._buf("local_counts", (L.per,), torch.int32)   # entries past this rank's share stay 0
-        if hi > lo:
-            t = np.ascontiguousarray(L.items[lo:hi])
+        L = self.layout(H, W, n_frames, mode)
+        rank = 0 if mode == "local" else self.rank
+        world = 1 if mode == "local" else self.world
+        t = np.ascontiguousarray(L.local_items(rank))
+        n_loc = len(t)
+        slots = L.local_slots()
+        local = self._buf("local_dets", (slots, cfg.max_det, self.stride), torch.float32)
+        lcount = self._buf("local_counts", (slots,), torch.int32)   # entries past this rank's share stay 0
+        t0 = time.perf_counter()
+        if n_loc:
+            dense = L.spread and n_loc != slots                       # blocks smaller than `per`: run dense, then pad per frame
+            dst = self._buf("dense_dets", (n_loc, cfg.max_det, self.stride), torch.float32) if dense else local
+            dcn = self._buf("dense_counts", (n_loc,), torch.int32) if dense else lcount
             _lib._check(_lib.lib().ffp_det_infer_tiles_dev(self.det.handle, d_frame.data_ptr(), H * n_frames, W, cfg.chan_order, _lib._ip(t),
-                                                           hi - lo, cfg.imgsz, cfg.conf, cfg.iou, cfg.max_det, 0, local.data_ptr(),
-                                                           lcount.data_ptr()))
-            self._truncate_shift(local, lcount, hi - lo, H * n_frames, W)
-        if hi - lo < L.per:
-            lcount[hi - lo:].zero_()
+                                                           n_loc, cfg.imgsz, cfg.conf, cfg.iou, cfg.max_det, 0, dst.data_ptr(), dcn.data_ptr()))
+            self._truncate_shift(dst, dcn, n_loc, H * n_frames, W)
+            if dense:
+                b = n_loc // n_frames
+                local.view(n_frames, L.per, cfg.max_det, self.stride)[:, :b].copy_(dst.view(n_frames, b, cfg.max_det, self.stride))
+                lcount.view(n_frames, L.per)[:, :b].copy_(dcn.view(n_frames, b))
+        if not L.spread and n_loc < slots:
+            lcount[n_loc:].zero_()
             torch.cuda.synchronize(self.dev)
-        need = self.world > 1 and (exchange == "always" or (exchange == "auto" and not L.aligned))
+        self.t_detect = time.perf_counter() - t0
+        self.t_exchange = 0.0
+        need = world > 1 and (L.spread or exchange == "always" or (exchange == "auto" and not L.aligned))
         if need:
-            g, gc = exchange_detections(local, lcount, self.world)
-            torch.cuda.synchronize(self.dev)       # libffp's stream must see the gathered boxes
+            t0 = time.perf_counter()
+            g, gc = exchange_detections(local, lcount, world)
+            if L.spread:
+                g, gc = frame_major(g, gc, world, n_frames, L.per)
+            # libffp's stream (the merge) must see the gathered boxes: stream-ordered through an event, the host does not wait
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            self.det.stream_wait_event(ev.cuda_event)
+            self._keep = (g, gc, ev)                                   # alive until the next call
+            self.t_exchange = time.perf_counter() - t0
             return g, gc, L, True
         return local, lcount, L, False
 
     def merge_frame_of(self, dets, counts, L: Layout, f: int, gathered: bool):
-        s0, ns = L.frame_slots(f, gathered, self.rank)
+        s0, ns = L.frame_slots(f, gathered, 0 if L.world == 1 else self.rank)
         return self.merge_frame(dets, counts, s0, ns)
 
     def _truncate_shift(self, dets, counts, n, H, W):

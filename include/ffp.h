@@ -209,6 +209,11 @@ int ffp_det_graph_status(ffp_det* d, int32_t* out_state);
  * 1: the head's nine towers and C3k's side convs run as parallel graph branches (3-5 % faster when the detector has the device
  * to itself, slower when an enhancer stream runs beside it); 2 / 3: coarser variants for A/B. Drops the cached plans. */
 int ffp_det_set_lanes(ffp_det* d, int mode);
+/* Stream interop for the multi-GPU exchange (no counterpart in the reference, which is single-device:
+ * /root/reference/pipeline_v4_yolo/app_yolo_sahi.py:136): work enqueued on the handle's stream AFTER this call waits for `hip_event`
+ * (a hipEvent_t of the same process, e.g. torch.cuda.Event.cuda_event recorded behind the RCCL all-gather of the boxes) — the
+ * merge that follows is ordered behind the collective without the host waiting for either. */
+int ffp_det_stream_wait_event(ffp_det* d, void* hip_event);
 
 /* ---------------------------------------------------------------------------------------------------------
  * single-operator entry points (layer-wise parity tests; host NHWC fp32 in/out, computed on `device` in `precision`)

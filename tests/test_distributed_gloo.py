@@ -126,3 +126,76 @@ def test_layout_alignment_and_lpt():
     loads = np.asarray([(sizes[a == r] ** 2).sum() for r in range(8)])
     assert loads.max() <= (sizes ** 2).sum() / 8 + (sizes ** 2).max()
     assert set(a.tolist()) <= set(range(8))
+
+
+def _worker_spread(rank, world, port, n_frames, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = pipeline.PipeConfig(slice_h=256, slice_w=256, imgsz=256)
+        items = pipeline.frame_items(540, 960, cfg, n_frames)
+        L = pipeline.Layout(items, n_frames, world, pipeline.item_costs(items, cfg.imgsz), spread=True)
+        mine = L.local_items(rank)
+        lo, hi = L.frame_bounds[rank]
+        b = hi - lo
+        assert len(mine) == n_frames * b and L.local_slots() == n_frames * L.per
+        # what FramePipeline.detect does: dense run over the rank's items, then padding to `per` slots per frame
+        dense = torch.zeros((n_frames * b, MAX_DET, STRIDE))
+        dcount = torch.zeros((n_frames * b,), dtype=torch.int32)
+        for k in range(len(mine)):
+            f, j = divmod(k, b)
+            i = f * L.ipf + lo + j
+            assert np.array_equal(mine[k], items[i])
+            d, n = fake_item_dets(i, items[i])
+            dense[k] = torch.from_numpy(d)
+            dcount[k] = n
+        local = torch.zeros((L.local_slots(), MAX_DET, STRIDE))
+        counts = torch.zeros((L.local_slots(),), dtype=torch.int32)
+        local.view(n_frames, L.per, MAX_DET, STRIDE)[:, :b].copy_(dense.view(n_frames, b, MAX_DET, STRIDE))
+        counts.view(n_frames, L.per)[:, :b].copy_(dcount.view(n_frames, b))
+        g, gc = pipeline.exchange_detections(local, counts, world)           # ONE all-gather for the whole group of frames
+        g, gc = pipeline.frame_major(g, gc, world, n_frames, L.per)
+        q.put((rank, g.numpy().copy(), gc.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 3), (3, 2)])
+def test_spread_group_one_gather_per_group(world, n_frames):
+    """The north_star split with several frames in flight (strong scaling): every frame's items over all ranks, ONE all-gather per
+    group of frames; after the frame-major reorder every rank holds, per frame, a contiguous slot range with that frame's detections
+    in SAHI's order — the input of the replicated merge."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_spread, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = pipeline.PipeConfig(slice_h=256, slice_w=256, imgsz=256)
+    items = pipeline.frame_items(540, 960, cfg, n_frames)
+    costs = pipeline.item_costs(items, cfg.imgsz)
+    L = pipeline.Layout(items, n_frames, world, costs, spread=True)
+    assert not L.aligned and all(L.owner(f) == -1 for f in range(n_frames))
+    assert all(L.rows_needed(r, 540) == (0, n_frames * 540) for r in range(world))
+    # every rank's share of a frame is a contiguous cost-balanced block of THAT frame
+    fb = L.frame_bounds
+    assert [b[0] for b in fb] + [L.ipf] == [0] + [b[1] for b in fb]
+    assert max(costs[lo:hi].sum() for lo, hi in fb) <= costs[:L.ipf].sum() / world + costs[:L.ipf].max()
+    exp = np.zeros((n_frames * world * L.per, MAX_DET, STRIDE), np.float32)
+    expc = np.zeros((n_frames * world * L.per,), np.int32)
+    for i in range(len(items)):
+        exp[L.slot(i)], expc[L.slot(i)] = fake_item_dets(i, items[i])
+    slots = [L.slot(i) for i in range(len(items))]
+    assert slots == sorted(slots) and len(set(slots)) == len(slots)
+    for _, g, gc in got:
+        assert np.array_equal(g, exp) and np.array_equal(gc, expc)
+    for f in range(n_frames):
+        s0, ns = L.frame_slots(f, True)
+        assert (s0, ns) == (f * world * L.per, world * L.per)
+        rows = np.concatenate([exp[k, :expc[k]] for k in range(s0, s0 + ns)], 0)
+        ref_rows = np.concatenate([fake_item_dets(i, items[i])[0][:fake_item_dets(i, items[i])[1]] for i in range(f * L.ipf, (f + 1) * L.ipf)], 0)
+        assert np.array_equal(rows, ref_rows)
