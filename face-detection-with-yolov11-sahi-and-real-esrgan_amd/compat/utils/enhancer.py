@@ -53,18 +53,19 @@ class RealESRGANer:
 
 
 def _imread_bgr(path):
+    """cv2.imread (a real OpenCV, or this build's shim: JPEG decoded on the GPU, pixel-identical to libjpeg-turbo): BGR or None."""
     try:
-        return np.asarray(Image.open(path).convert("RGB"))[..., ::-1].copy()
+        import cv2
+        return cv2.imread(str(path))
     except Exception:
         return None
 
 
 def _imwrite_bgr(path, img, quality=95):
+    """cv2.imwrite with [IMWRITE_JPEG_QUALITY, quality] (the shim encodes .jpg on the GPU, byte-identical to libjpeg-turbo)."""
     try:
-        ext = os.path.splitext(path)[1].lower()
-        pil = Image.fromarray(np.ascontiguousarray(img[..., ::-1]))
-        pil.save(path, quality=quality) if ext in (".jpg", ".jpeg") else pil.save(path)
-        return True
+        import cv2
+        return bool(cv2.imwrite(str(path), np.ascontiguousarray(img), [cv2.IMWRITE_JPEG_QUALITY, int(quality)]))
     except Exception:
         return False
 

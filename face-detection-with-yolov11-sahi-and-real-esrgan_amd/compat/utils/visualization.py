@@ -23,20 +23,19 @@ def _rgb(bgr):
 
 
 def _imread_bgr(path):
+    """cv2.imread (a real OpenCV, or this build's shim: JPEG decoded on the GPU, pixel-identical to libjpeg-turbo): BGR or None."""
     try:
-        return np.asarray(Image.open(path).convert("RGB"))[..., ::-1].copy()
+        import cv2
+        return cv2.imread(str(path))
     except Exception:
         return None
 
 
 def _imwrite_bgr(path, img, quality=95):
+    """cv2.imwrite with [IMWRITE_JPEG_QUALITY, quality] (the shim encodes .jpg on the GPU, byte-identical to libjpeg-turbo)."""
     try:
-        pil = Image.fromarray(np.ascontiguousarray(img[..., ::-1]))
-        if os.path.splitext(path)[1].lower() in (".jpg", ".jpeg"):
-            pil.save(path, quality=quality)
-        else:
-            pil.save(path)
-        return True
+        import cv2
+        return bool(cv2.imwrite(str(path), np.ascontiguousarray(img), [cv2.IMWRITE_JPEG_QUALITY, int(quality)]))
     except Exception:
         return False
 
