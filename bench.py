@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 
 # dense MFMA peaks (/opt/skills/guides/MI355X_MICROARCH.md); f32x3 spends three fp16 MFMAs per algorithmic product
 PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32x3": 2500.0 / 3}
+# what a bare MFMA loop on random operands sustains on this chip (tools/probes/mfma_peak.hip, profiles/r03_mfma_sustained_peak_probe.txt):
+# the clock drops under matrix load (DVFS), so the 2.4 GHz figures above are not reachable by any kernel; context only, `frac` uses PEAK_TFLOPS
+SUSTAINED_TFLOPS = {"f16": 1908.0, "f32x3": 1677.0 / 3}
 
 
 def parse():
@@ -512,21 +515,29 @@ def main():
             r = None
             try:
                 steps_r = kw.pop("steps", ss)
+                prof_sr = kw.pop("profile_sr", False)
                 r = Runner(args, ctx, pipe=pipe, **kw)
-                d = r.timed(sw, steps_r, profile_last=False)
+                d = r.timed(sw, steps_r, profile_last=prof_sr)
                 rep = r.report(steps_r)
                 secondary[name] = {"value": round(r.B * steps_r / d, 3), "unit": "frames/s", "ms_per_step": round(d / steps_r * 1e3, 3), "steps": steps_r, "workload": r.describe(),
                                    "frames_per_step": r.B, "det_batch_frames": r.DB, "sr_batch_frames": r.SB, "mode": r.mode, "gathered": bool(r.state.get("gathered", False)),
                                    "latency_ms_rank0": rep[0]["latency_ms"]}
                 if world > 1:
                     secondary[name]["per_rank"] = rep
+                if prof_sr and pipe.sr is not None:         # the dominant kernel at THIS row's launch sizes
+                    top = max(pipe.sr.profile(), key=lambda q: q["ms"], default=None)
+                    if top and top["ms"] > 0:
+                        ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
+                        secondary[name]["roofline_dominant"] = {"kernel": top["variant"], "achieved": round(ach, 2), "peak": PEAK_TFLOPS["f16"], "unit": "TFLOP/s",
+                                                                "frac": round(ach / PEAK_TFLOPS["f16"], 4), "launches": top["launches"],
+                                                                "avg_launch_us": round(top["ms"] * 1e3 / max(top["launches"], 1), 2)}
             except Exception as e:      # noqa: BLE001
                 secondary[name] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
                 print(f"[bench] secondary row {name} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
             return r
 
         # the reference's own order: strictly one frame, one SR pass at a time (docs sahi/predict.py:226,270) — nothing batched across frames
-        sec("frame_by_frame", det_batch=1, sr_batch=1)
+        sec("frame_by_frame", det_batch=1, sr_batch=1, profile_sr=True)
         sec("steps_200", steps=200)                       # the headline configuration over a 10x longer timed region
         sec("frames_resident_in_hbm", resident=True)
         if args.sr_crops > 0 and args.sr_sizes != "fixed":
@@ -554,7 +565,7 @@ def main():
         roof = None
         pmc = {}
         pmc_src = None
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # HBM bytes per launch from the committed PMC passes, keyed by kernel variant
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # HBM bytes per launch from the committed PMC passes, keyed by kernel variant
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     pmc = json.load(fh).get("kernels", {})
@@ -572,7 +583,9 @@ def main():
                     "traffic": (round(pmc[d["variant"]]["hbm_bytes_per_launch"]) if d["variant"] in pmc else None),
                     "traffic_source": (f"profiles/{pmc_src} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if d["variant"] in pmc else None),
                     "launches": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2),
-                    "flops_per_launch": d["flops"] / max(d["launches"], 1)}
+                    "flops_per_launch": d["flops"] / max(d["launches"], 1),
+                    "sustained_mfma_loop": ({"tflops": SUSTAINED_TFLOPS[dtp], "frac_of_it": round(ach / SUSTAINED_TFLOPS[dtp], 4),
+                                             "source": "profiles/r03_mfma_sustained_peak_probe.txt (bare MFMA loop, random operands, this chip)"} if dtp in SUSTAINED_TFLOPS else None)}
         res = {
             "metric": "end-to-end 4K frames/sec (SAHI+YOLOv11s+ESRGAN×4)", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),

@@ -24,6 +24,10 @@
 
 #include "conv_args.hpp"
 
+#ifndef FFP_R16_DBG
+#define FFP_R16_DBG 0          // 1: honour the phase-skip bits of ConvArgs::dbg beyond bit 1 (tools/rows16_phase_probe.py)
+#endif
+
 namespace ffp {
 
 namespace {
@@ -52,6 +56,8 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // phase-skip bits: 1 epilogue, 2 MFMA, 4 staging requests, 8 staging LDS writes, 16 fragment reads, 32 barriers
+  const int DBG = FFP_R16_DBG ? a.dbg : (a.dbg & 1);
   const int pc = lane & 15, g = lane >> 4;             // pixel column inside the tile, channel group / k slot
 
   // ---- this workgroup's items: logical ids first + j * Ws, j < J --------------------------------------------------------------
@@ -132,6 +138,7 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
   };
   uint4 ra[NP], rb[NP];                                // two register sets
   auto piece_fetch = [&](int p, uint4& r) {            // slot p of the prefetch cursor's chunk -> r
+    if (DBG & 4) return;
     if (p < 5) {
       r = bload(rs_in, isrc[p] != OOB ? isrc[p] + (unsigned)(pf_c * 64) : OOB);
     } else if (p < 9) {
@@ -142,6 +149,7 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
     }
   };
   auto piece_stash = [&](unsigned char* sb, int p, const uint4& r) {
+    if (DBG & 8) return;
     if (p < 5) *reinterpret_cast<uint4*>(sb + idst[p]) = r;
     else if (p < 9) *reinterpret_cast<uint4*>(sb + G::IN_BYTES + wrel[p - 5]) = r;
     else *reinterpret_cast<uint4*>(sb + (s9_in ? idst[5] : G::IN_BYTES + wrel[4])) = r;
@@ -199,11 +207,13 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
   auto chunk = [&](const unsigned char* sb, unsigned char* sbn, uint4 (&set)[NP]) {
     uint4 bq[2][6], aq[3][2];
     auto ldB = [&](int kx, int q) {
+      if (DBG & 16) return;
 #pragma unroll
       for (int j = 0; j < 6; ++j) bq[q][j] = *reinterpret_cast<const uint4*>(sb + boff[kx] + j * 1152);
     };
     auto ldA = [&](int s, int q) {                             // step s = (kx, ky) = (s / 3, s % 3); packed tap index ky * 3 + kx
       const int tap = (s % 3) * 3 + s / 3;
+      if (DBG & 16) return;
 #pragma unroll
       for (int m = 0; m < 2; ++m) aq[q][m] = *reinterpret_cast<const uint4*>(sb + aoff + ((tap * 2 + m) << 10));
     };
@@ -226,6 +236,7 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
+          if (DBG & 2) continue;
           union { uint4 u; f16x8 h; } ua, ub;
           ua.u = aq[s % 3][m]; ub.u = bq[kx & 1][i + ky];
           acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ua.h, ub.h, acc[i][m], 0, 0, 0);
@@ -296,7 +307,7 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
   int cj = 0, cc = 0;                                  // compute cursor: item, chunk
   auto finish_chunk = [&]() {
     if (++cc == NC) {
-      if (!(a.dbg & 1)) epilogue(cj);
+      if (!(DBG & 1)) epilogue(cj);
       zero_acc();
       cc = 0; ++cj;
     }
@@ -311,11 +322,11 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
     // stage 0 holds chunk q; rb holds chunk q+1 (-> stage 1), its registers are re-requested for chunk q+3
     chunk(smem, smem + G::STAGE, rb);
     finish_chunk();
-    __syncthreads();
+    if (!(DBG & 32)) __syncthreads();
     if (q + 1 >= Q) break;
     chunk(smem + G::STAGE, smem, ra);
     finish_chunk();
-    __syncthreads();
+    if (!(DBG & 32)) __syncthreads();
   }
 }
 

@@ -21,6 +21,11 @@ def variant(sym: str):
         nw, mi, nt = int(m.group(1)), int(m.group(2)), int(m.group(3))
         stream = m.group(6) in ("true", "1")
         return f"f32x3_k1s1_pw{mi}x{nt}" + ("s" if stream else "w" if nw == 8 else "")
+    m = re.search(r"conv_k3d_kernel<(\d+), *(\d+), *(\d+), *(\d+), *(\d+)>", sym) or re.search(r"conv_k3d_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", sym)
+    if m:                                                   # stride, wave grid, pixel fragments and channel tiles per wave (conv_k3d.hip)
+        s_, wm, wn, mi, niw = (int(v) for v in m.groups())
+        name = {(2, 2, 2, 2): "d128", (2, 2, 2, 1): "d64", (4, 1, 1, 1): "d32", (2, 2, 4, 2): "d128x256", (2, 2, 4, 1): "d64x256"}.get((wm, wn, mi, niw), f"d{wm}{wn}{mi}{niw}")
+        return f"f32x3_k3s{s_}_{name}"
     m = re.search(r"conv_rows_kernel<(\d+), *(\d+)>", sym) or re.search(r"conv_rows_kernelILi(\d+)ELi(\d+)E", sym)
     if m:
         return "f16_k3s1_rows"
