@@ -25,8 +25,8 @@
 #include "conv_args.hpp"
 
 #ifndef FFP_R16_DBG
-#define FFP_R16_DBG 0          // 1: honour the phase-skip bits of ConvArgs::dbg beyond bit 1 (tools/rows16_phase_probe.py)
-#endif
+#define FFP_R16_DBG 0          // 1: also build the phase-skip instantiations of the kernel (tools/rows16_phase_probe.py); compile-time masks, so
+#endif                         //    that what is left keeps the production kernel's instruction schedule
 
 namespace ffp {
 
@@ -49,6 +49,7 @@ struct R16Geo {
 // Items are dealt so that each XCD (workgroups b, b + 8, ... share one) gets a contiguous run of logical ids (pixel tile x
 // 32-channel block) and the workgroups of an XCD take consecutive ids at the same time: the channel blocks of a pixel tile
 // and neighbouring tiles meet in that XCD's L2. The mapping only affects speed.
+template <int DBG>             // phase-skip bits: 1 epilogue, 2 MFMA, 4 staging requests, 8 staging LDS writes, 16 fragment reads, 32 barriers
 __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
   using G = R16Geo;
   constexpr int NP = G::NP;
@@ -56,8 +57,6 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // phase-skip bits: 1 epilogue, 2 MFMA, 4 staging requests, 8 staging LDS writes, 16 fragment reads, 32 barriers
-  const int DBG = FFP_R16_DBG ? a.dbg : (a.dbg & 1);
   const int pc = lane & 15, g = lane >> 4;             // pixel column inside the tile, channel group / k slot
 
   // ---- this workgroup's items: logical ids first + j * Ws, j < J --------------------------------------------------------------
@@ -136,7 +135,7 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
       isrc[i] = ok ? (unsigned)(((iy >> a.up) * Wi + (ix >> a.up)) * a.in_cs * 2 + s * 16) : OOB;
     }
   };
-  uint4 ra[NP], rb[NP];                                // two register sets
+  uint4 ra[NP] = {}, rb[NP] = {};                      // two register sets
   auto piece_fetch = [&](int p, uint4& r) {            // slot p of the prefetch cursor's chunk -> r
     if (DBG & 4) return;
     if (p < 5) {
@@ -149,7 +148,7 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
     }
   };
   auto piece_stash = [&](unsigned char* sb, int p, const uint4& r) {
-    if (DBG & 8) return;
+    if (DBG & 8) { asm volatile("" :: "v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w)); return; }      // the requests stay alive without the writes
     if (p < 5) *reinterpret_cast<uint4*>(sb + idst[p]) = r;
     else if (p < 9) *reinterpret_cast<uint4*>(sb + G::IN_BYTES + wrel[p - 5]) = r;
     else *reinterpret_cast<uint4*>(sb + (s9_in ? idst[5] : G::IN_BYTES + wrel[4])) = r;
@@ -205,15 +204,23 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
   // `set`, requested two chunks ago) is written to the other LDS stage and the same register is re-requested for the chunk three
   // ahead — 10 ds_write + 10 buffer loads per chunk, issued between MFMAs instead of in a phase of their own.
   auto chunk = [&](const unsigned char* sb, unsigned char* sbn, uint4 (&set)[NP]) {
-    uint4 bq[2][6], aq[3][2];
+    uint4 bq[2][6] = {}, aq[3][2] = {};
     auto ldB = [&](int kx, int q) {
-      if (DBG & 16) return;
+      if (DBG & 16) {                                          // opaque operands instead of fragment reads
+#pragma unroll
+        for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(bq[q][j].x), "+v"(bq[q][j].y), "+v"(bq[q][j].z), "+v"(bq[q][j].w));
+        return;
+      }
 #pragma unroll
       for (int j = 0; j < 6; ++j) bq[q][j] = *reinterpret_cast<const uint4*>(sb + boff[kx] + j * 1152);
     };
     auto ldA = [&](int s, int q) {                             // step s = (kx, ky) = (s / 3, s % 3); packed tap index ky * 3 + kx
       const int tap = (s % 3) * 3 + s / 3;
-      if (DBG & 16) return;
+      if (DBG & 16) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) asm volatile("" : "+v"(aq[q][m].x), "+v"(aq[q][m].y), "+v"(aq[q][m].z), "+v"(aq[q][m].w));
+        return;
+      }
 #pragma unroll
       for (int m = 0; m < 2; ++m) aq[q][m] = *reinterpret_cast<const uint4*>(sb + aoff + ((tap * 2 + m) << 10));
     };
@@ -307,7 +314,12 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
   int cj = 0, cc = 0;                                  // compute cursor: item, chunk
   auto finish_chunk = [&]() {
     if (++cc == NC) {
-      if (!(DBG & 1)) epilogue(cj);
+      if (!(DBG & 1)) {
+        epilogue(cj);
+      } else {                                                   // keep the sums alive without the epilogue
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(acc[i][0]), "v"(acc[i][1]));
+      }
       zero_acc();
       cc = 0; ++cj;
     }
@@ -332,9 +344,29 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
 
 }  // namespace
 
-void conv_rows16_init() {
-  FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R16Geo::LDS));
+namespace {
+#if FFP_R16_DBG
+constexpr int kR16Masks[] = {0, 1, 2, 12, 16, 32, 13, 29, 61, 19, 31, 63};
+#else
+constexpr int kR16Masks[] = {0, 1};
+#endif
+template <int I = 0> void r16_for_mask(int mask, bool init, const ConvArgs* a, unsigned grid, hipStream_t st) {
+  if constexpr (I < (int)(sizeof(kR16Masks) / sizeof(int))) {
+    if (init) {
+      FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows16_kernel<kR16Masks[I]>), hipFuncAttributeMaxDynamicSharedMemorySize, R16Geo::LDS));
+      r16_for_mask<I + 1>(mask, init, a, grid, st);
+    } else if (mask == kR16Masks[I]) {
+      hipLaunchKernelGGL(conv_rows16_kernel<kR16Masks[I]>, dim3(grid), dim3(256), R16Geo::LDS, st, *a);
+    } else {
+      r16_for_mask<I + 1>(mask, init, a, grid, st);
+    }
+  } else if (!init) {
+    fail(FFP_ERR_ARG, "rows16: phase-skip mask %d is not built (FFP_R16_DBG)", mask);
+  }
 }
+}  // namespace
+
+void conv_rows16_init() { r16_for_mask<>(0, true, nullptr, 0, nullptr); }
 
 bool conv_rows16_eligible(const ConvOp& op, const ConvArgs& a) {
   const PackedConv& pc = *op.pc;
@@ -360,7 +392,7 @@ void launch_conv_rows16(ConvArgs& a, const PackedConv& pc, Level* out_lvl, hipSt
   long long ws = std::max<long long>(64, (per_xcd + G::TCAP - 1) / G::TCAP);
   ws = (ws + a.n_nblk - 1) / a.n_nblk * a.n_nblk;
   FFP_CHECK(8 * ws < (1ll << 31) && (per_xcd + ws - 1) / ws <= G::TCAP, FFP_ERR_STATE, "rows16: launch geometry");
-  hipLaunchKernelGGL(conv_rows16_kernel, dim3((unsigned)(8 * ws)), dim3(256), G::LDS, st, a);
+  r16_for_mask<>(a.dbg, false, &a, (unsigned)(8 * ws), st);
 }
 
 }  // namespace ffp

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ffp_amd  # noqa
 from ffp_amd import _lib
-masks = [0, 1, 2, 4, 8, 16, 32, 12, 1 | 12, 1 | 12 | 16, 1 | 12 | 16 | 32, 1 | 2 | 16, 1 | 2 | 12 | 16, 63]
+masks = [0, 1, 2, 12, 16, 32, 13, 29, 61, 19, 31, 63]
 for n, cin, cout in ((2048, 128, 32), (2048, 64, 32), (2048, 192, 64)):
     flops = 2.0 * cin * cout * 9 * 256 * n
     row = []
