@@ -127,6 +127,7 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
   // ---- staging: a chunk = NPIECE wave-pieces; wave w stages pieces w, w + 4, ...: lane -> (halo pixel, 4-channel quarter) ----------------
   unsigned isrc[NPW];      // byte offset of the lane's vector of the item being PREFETCHED from its image base (chunk 0); OOB: zeros
   unsigned idst[NPW];      // LDS byte offset of the lane's hi half inside a stage (item independent); the lo half sits at idst ^ 32
+  unsigned hyx[NPW];       // the piece's halo pixel and quarter (quarter << 16 | row << 8 | column), 0xFFFF: padding pixel
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
     const int idx = (wave + 4 * i) * 64 + lane;
@@ -135,6 +136,7 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
     const int rec = px < NPX ? rec_of(hy, hx) : px;                    // padding pixels: records of their own past the image
     const int x = px < NPX ? swz_of(hy, hx) : 0;
     idst[i] = (unsigned)(rec * 64 + (((q >> 1) ^ x) << 4) + ((q & 1) << 3));
+    hyx[i] = px < NPX ? (unsigned)((q << 16) | (hy << 8) | hx) : 0xFFFFu;      // item independent: an item's set-up is adds and compares, no division
   }
   int pf_item = 0, pf_c = 0;                           // prefetch cursor: two chunks ahead of the MFMAs
   auto setup_pf = [&](int j) {
@@ -144,11 +146,9 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
     rs_in = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(inb), 0, 0x7FFFFFF0, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
-      const int idx = (wave + 4 * i) * 64 + lane;
-      const int px = idx >> 2, q = idx & 3;
-      const int hy = px / HWD, hx = px - hy * HWD;
+      const int hy = (int)(hyx[i] >> 8) & 0xFF, hx = (int)hyx[i] & 0xFF, q = (int)(hyx[i] >> 16);
       const int iy = oy0 * S - 1 + hy, ix = ox0 * S - 1 + hx;
-      const bool ok = px < NPX && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+      const bool ok = (hyx[i] & 0xFFFFu) != 0xFFFFu && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
       isrc[i] = ok ? (unsigned)((iy * Wi + ix) * a.in_cs * 4 + q * 16) : OOB;
     }
   };

@@ -1052,7 +1052,7 @@ bool conv_pw_enabled() {
 
 static bool use_rows16(const ConvOp& op, const ConvArgs& a) {
   if (!conv_rows16_eligible(op, a)) return false;
-  return a.force_shape == 9 || (a.force_shape < 0 && conv_rows16_enabled());
+  return a.force_shape == 9 || a.force_shape == 23 || (a.force_shape < 0 && conv_rows16_enabled());
 }
 
 void launch_conv(const ConvOp& op, hipStream_t st) {

@@ -21,12 +21,17 @@
 // fragment reads (ds_read_b128, lane = column x slot) are bank-conflict free for every row and horizontal tap
 // (SQ_LDS_BANK_CONFLICT = 0 measured); weight fragments are lane-linear. Two stages of 39 KiB: two workgroups per CU.
 #include <algorithm>
+#include <cstdlib>
 
 #include "conv_args.hpp"
 
 #ifndef FFP_R16_DBG
 #define FFP_R16_DBG 0          // 1: also build the phase-skip instantiations of the kernel (tools/rows16_phase_probe.py); compile-time masks, so
 #endif                         //    that what is left keeps the production kernel's instruction schedule
+
+#ifndef FFP_R16_STAMP
+#define FFP_R16_STAMP 0        // 1: diagnostic build — s_memtime stamps around the phases of every chunk, sums printed by the first workgroups
+#endif                         //    (MI355X guide, "In-kernel stamps"); never in a shipped build, the stamps cost ~10 % of the kernel
 
 namespace ffp {
 
@@ -44,15 +49,22 @@ struct R16Geo {
   static constexpr int TCAP = 40;                             // work items one workgroup walks (descriptor table in LDS)
   static constexpr int DESC = 2 * STAGE;                      // int4 x 3 per item: tile {img, y0, x0}, input {base, h, w}, output {base, h, w}
   static constexpr int LDS = 2 * STAGE + TCAP * 48;           // 81792 <= 80 KiB
+  // weight-resident form (RES): [input stage 0][input stage 1][all chunks' weight fragments of the workgroup's channel block][descriptors];
+  // one workgroup per CU, the weights are fetched ONCE per workgroup instead of once per tile
+  static constexpr int NPR = 6;                               // staging slots per wave and chunk: 5 input pieces + input piece 20 (every wave, same bytes)
+  static constexpr int RES_W = 2 * IN_BYTES;                  // offset of the resident weights
+  static constexpr int RES_MAXC = 6;                          // chunks (cin <= 192)
+  static constexpr int res_lds(int nc) { return 2 * IN_BYTES + nc * W_BYTES + TCAP * 48; }
 };
 
 // Items are dealt so that each XCD (workgroups b, b + 8, ... share one) gets a contiguous run of logical ids (pixel tile x
 // 32-channel block) and the workgroups of an XCD take consecutive ids at the same time: the channel blocks of a pixel tile
 // and neighbouring tiles meet in that XCD's L2. The mapping only affects speed.
-template <int DBG>             // phase-skip bits: 1 epilogue, 2 MFMA, 4 staging requests, 8 staging LDS writes, 16 fragment reads, 32 barriers
-__global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
+template <int DBG, bool RES = false>             // phase-skip bits: 1 epilogue, 2 MFMA, 4 staging requests, 8 staging LDS writes, 16 fragment reads, 32 barriers
+__global__ void __launch_bounds__(256, (RES ? 1 : 2)) conv_rows16_kernel(const ConvArgs a) {
   using G = R16Geo;
-  constexpr int NP = G::NP;
+  constexpr int NP = RES ? G::NPR : G::NP;
+  constexpr int STG = RES ? G::IN_BYTES : G::STAGE;            // bytes of one LDS stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -71,7 +83,8 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
   if (J == 0) return;
   const int nt0 = first % a.n_nblk;                    // Ws and per_xcd are multiples of n_nblk: ONE channel block per workgroup
 
-  int4* desc = reinterpret_cast<int4*>(smem + G::DESC);
+  const int NC = a.cin >> 5;
+  int4* desc = reinterpret_cast<int4*>(smem + (RES ? G::RES_W + NC * G::W_BYTES : G::DESC));
   if (tid < J) {
     const int4 t = a.tiles[(first + tid * Ws) / a.n_nblk];
     desc[tid * 3] = t;
@@ -87,7 +100,6 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
     return reinterpret_cast<unsigned char*>(((unsigned long long)hi << 32) | lo);
   };
   auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-  const int NC = a.cin >> 5;
   const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.wpk) + (long long)nt0 * NC * G::W_BYTES;
   const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(wb), 0, 0x7FFFFFF0, 0x00020000);
   auto rs_in = rs_w;                                   // rebuilt per item (setup_pf)
@@ -106,12 +118,14 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
   unsigned isrc[6];        // byte offset of (pixel, slot) of the item being PREFETCHED from its image base; OOB: zeros
   unsigned idst[6];        // LDS byte offset of that vector inside the stage (item independent)
   unsigned wrel[5];        // weight pieces: byte offset inside a chunk's 18 KiB, also the LDS offset behind IN_BYTES
+  unsigned hyx[6];         // the slot's halo pixel and vector slot (slot << 16 | row << 8 | column): item independent, so that an item's set-up is adds and compares
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const int idx = (i < 5 ? wave + 4 * i : 20) * 64 + lane;
     const int px = idx >> 2, s = idx & 3;
     const int hy = px / 18, hx = px - hy * 18;
     idst[i] = (unsigned)(px * 64 + ((s ^ ((hx >> 1) & 2)) << 4));
+    hyx[i] = px < 324 ? (unsigned)((s << 16) | (hy << 8) | hx) : (unsigned)((s << 16) | 0xFFFF);
   }
 #pragma unroll
   for (int i = 0; i < 5; ++i) wrel[i] = (unsigned)(((i < 4 ? wave + 4 * i : s9_piece) * 64 + lane) * 16);
@@ -119,6 +133,10 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
   // per-lane offset serves the load (chunk offset as the instruction's scalar operand) and the LDS write
 
   int pf_item = 0, pf_c = 0;                           // prefetch cursor: three chunks ahead of the MFMAs
+  int cj = 0, cc = 0;                                  // compute cursor: item, chunk
+#if FFP_R16_STAMP
+  unsigned long long st_t1 = 0, st_sum[4] = {0, 0, 0, 0};     // exposed first fragment reads, MFMA stream, epilogue + bookkeeping, barrier
+#endif
   auto setup_pf = [&](int j) {
     const int4 t = desc[j * 3], it = desc[j * 3 + 1];
     const int oy0 = sgpr(t.y), ox0 = sgpr(t.z), Hi = sgpr(it.y), Wi = sgpr(it.z);
@@ -126,18 +144,21 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
     const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in) + ((long long)sgpr(it.x) * a.in_cs + a.in_coff) * 2;
     rs_in = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(inb), 0, 0x7FFFFFF0, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int idx = (i < 5 ? wave + 4 * i : 20) * 64 + lane;
-      const int px = idx >> 2, s = idx & 3;
-      const int hy = px / 18, hx = px - hy * 18;
+    for (int i = 0; i < 6; ++i) {                      // hyx[i]: the slot's halo pixel (row << 8 | column) and vector slot, fixed per lane; 0xFFFF: padding pixel
+      const int hy = (int)(hyx[i] >> 8) & 0xFF, hx = (int)hyx[i] & 0xFF, sl = (int)(hyx[i] >> 16) & 3;
       const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-      const bool ok = px < 324 && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-      isrc[i] = ok ? (unsigned)(((iy >> a.up) * Wi + (ix >> a.up)) * a.in_cs * 2 + s * 16) : OOB;
+      const bool ok = (hyx[i] & 0xFFFFu) != 0xFFFFu && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+      isrc[i] = ok ? (unsigned)(((iy >> a.up) * Wi + (ix >> a.up)) * a.in_cs * 2 + sl * 16) : OOB;
     }
   };
   uint4 ra[NP] = {}, rb[NP] = {};                      // two register sets
   auto piece_fetch = [&](int p, uint4& r) {            // slot p of the prefetch cursor's chunk -> r
     if (DBG & 4) return;
+    if constexpr (RES) {                               // input pieces only: slots 0..4 as below, slot 5 = input piece 20 for every wave
+      const unsigned o = isrc[p];
+      r = bload(rs_in, o != OOB ? o + (unsigned)(pf_c * 64) : OOB);
+      return;
+    }
     if (p < 5) {
       r = bload(rs_in, isrc[p] != OOB ? isrc[p] + (unsigned)(pf_c * 64) : OOB);
     } else if (p < 9) {
@@ -149,6 +170,7 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
   };
   auto piece_stash = [&](unsigned char* sb, int p, const uint4& r) {
     if (DBG & 8) { asm volatile("" :: "v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w)); return; }      // the requests stay alive without the writes
+    if constexpr (RES) { *reinterpret_cast<uint4*>(sb + idst[p]) = r; return; }
     if (p < 5) *reinterpret_cast<uint4*>(sb + idst[p]) = r;
     else if (p < 9) *reinterpret_cast<uint4*>(sb + G::IN_BYTES + wrel[p - 5]) = r;
     else *reinterpret_cast<uint4*>(sb + (s9_in ? idst[5] : G::IN_BYTES + wrel[4])) = r;
@@ -205,6 +227,7 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
   // ahead — 10 ds_write + 10 buffer loads per chunk, issued between MFMAs instead of in a phase of their own.
   auto chunk = [&](const unsigned char* sb, unsigned char* sbn, uint4 (&set)[NP]) {
     uint4 bq[2][6] = {}, aq[3][2] = {};
+    const unsigned char* wres = smem + (G::RES_W - G::IN_BYTES) + cc * G::W_BYTES;       // RES: this chunk's resident weights (aoff carries IN_BYTES)
     auto ldB = [&](int kx, int q) {
       if (DBG & 16) {                                          // opaque operands instead of fragment reads
 #pragma unroll
@@ -222,12 +245,16 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
         return;
       }
 #pragma unroll
-      for (int m = 0; m < 2; ++m) aq[q][m] = *reinterpret_cast<const uint4*>(sb + aoff + ((tap * 2 + m) << 10));
+      for (int m = 0; m < 2; ++m) aq[q][m] = *reinterpret_cast<const uint4*>((RES ? wres : sb) + aoff + ((tap * 2 + m) << 10));
     };
     ldB(0, 0);
     ldA(0, 0);
     ldA(1, 1);
     __builtin_amdgcn_sched_barrier(0);
+#if FFP_R16_STAMP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    st_t1 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
       const int kx = s / 3, ky = s - 3 * kx;
@@ -235,7 +262,7 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
       if (ky == 0 && kx < 2) ldB(kx + 1, (kx + 1) & 1);
       // staging slots per step: {0} {1} {2} {3} {4} {5} {6} {7} {8, 9}
 #pragma unroll
-      for (int p = s; p < (s == 8 ? 10 : s + 1); ++p) {
+      for (int p = s; p < (RES ? (s < NP ? s + 1 : s) : (s == 8 ? 10 : s + 1)); ++p) {
         piece_stash(sbn, p, set[p]);
         piece_fetch(p, set[p]);
       }
@@ -311,7 +338,6 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
   // ---- the chunk stream: chunk q (of all items, back to back) is multiplied out of stage q & 1 while chunk q+1 moves from its
   // register set into the other stage and chunks q+2, q+3 are in flight -----------------------------------------------------------------
   const int Q = J * NC;
-  int cj = 0, cc = 0;                                  // compute cursor: item, chunk
   auto finish_chunk = [&]() {
     if (++cc == NC) {
       if (!(DBG & 1)) {
@@ -324,6 +350,19 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
       cc = 0; ++cj;
     }
   };
+  if constexpr (RES) {
+    // the workgroup's weights, all chunks, once: NC x 18 wave-pieces, eight in flight per wave; visible to all after the barrier below
+    const int n_wp = NC * 18;
+    for (int p0 = wave; p0 < n_wp; p0 += 32) {
+      uint4 t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (p0 + 4 * k < n_wp) t[k] = bload(rs_w, (unsigned)lane * 16u, sgpr((p0 + 4 * k) << 10));
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (p0 + 4 * k < n_wp) *reinterpret_cast<uint4*>(smem + G::RES_W + ((p0 + 4 * k) << 10) + lane * 16) = t[k];
+    }
+  }
   setup_pf(0);
   fetch_all(ra);
   fetch_all(rb);
@@ -332,14 +371,36 @@ __global__ void __launch_bounds__(256, 2) conv_rows16_kernel(const ConvArgs a) {
   __syncthreads();
   for (int q = 0; q < Q; q += 2) {
     // stage 0 holds chunk q; rb holds chunk q+1 (-> stage 1), its registers are re-requested for chunk q+3
-    chunk(smem, smem + G::STAGE, rb);
+#if FFP_R16_STAMP
+#define R16_PHASES(SB, SBN, SET)                                                      \
+    {                                                                                 \
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();                     \
+      chunk(SB, SBN, SET);                                                            \
+      const unsigned long long t2 = __builtin_amdgcn_s_memtime();                     \
+      finish_chunk();                                                                 \
+      const unsigned long long t3 = __builtin_amdgcn_s_memtime();                     \
+      __syncthreads();                                                                \
+      const unsigned long long t4 = __builtin_amdgcn_s_memtime();                     \
+      st_sum[0] += st_t1 - t0; st_sum[1] += t2 - st_t1; st_sum[2] += t3 - t2; st_sum[3] += t4 - t3; \
+    }
+    R16_PHASES(smem, smem + STG, rb)
+    if (q + 1 >= Q) break;
+    R16_PHASES(smem + STG, smem, ra)
+#else
+    chunk(smem, smem + STG, rb);
     finish_chunk();
     if (!(DBG & 32)) __syncthreads();
     if (q + 1 >= Q) break;
-    chunk(smem + G::STAGE, smem, ra);
+    chunk(smem + STG, smem, ra);
     finish_chunk();
     if (!(DBG & 32)) __syncthreads();
+#endif
   }
+#if FFP_R16_STAMP
+  if (lane == 0 && (blockIdx.x % 37) == 0 && blockIdx.x < 512)
+    printf("r16stamp wg %d wave %d chunks %d items %d : first_frag_reads %llu stream %llu (ideal %d) epilogue+setup %llu barrier %llu cycles per chunk\n", (int)blockIdx.x, wave, Q, J,
+           st_sum[0] / Q, st_sum[1] / Q, 72 * 16, st_sum[2] / Q, st_sum[3] / Q);
+#endif
 }
 
 }  // namespace
@@ -350,15 +411,17 @@ constexpr int kR16Masks[] = {0, 1, 2, 12, 16, 32, 13, 29, 61, 19, 31, 63};
 #else
 constexpr int kR16Masks[] = {0, 1};
 #endif
-template <int I = 0> void r16_for_mask(int mask, bool init, const ConvArgs* a, unsigned grid, hipStream_t st) {
+template <int I = 0> void r16_for_mask(int mask, bool res, bool init, const ConvArgs* a, unsigned grid, int lds, hipStream_t st) {
   if constexpr (I < (int)(sizeof(kR16Masks) / sizeof(int))) {
     if (init) {
-      FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows16_kernel<kR16Masks[I]>), hipFuncAttributeMaxDynamicSharedMemorySize, R16Geo::LDS));
-      r16_for_mask<I + 1>(mask, init, a, grid, st);
+      FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows16_kernel<kR16Masks[I], false>), hipFuncAttributeMaxDynamicSharedMemorySize, R16Geo::LDS));
+      FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows16_kernel<kR16Masks[I], true>), hipFuncAttributeMaxDynamicSharedMemorySize, R16Geo::res_lds(R16Geo::RES_MAXC)));
+      r16_for_mask<I + 1>(mask, res, init, a, grid, lds, st);
     } else if (mask == kR16Masks[I]) {
-      hipLaunchKernelGGL(conv_rows16_kernel<kR16Masks[I]>, dim3(grid), dim3(256), R16Geo::LDS, st, *a);
+      if (res) hipLaunchKernelGGL((conv_rows16_kernel<kR16Masks[I], true>), dim3(grid), dim3(256), lds, st, *a);
+      else hipLaunchKernelGGL((conv_rows16_kernel<kR16Masks[I], false>), dim3(grid), dim3(256), lds, st, *a);
     } else {
-      r16_for_mask<I + 1>(mask, init, a, grid, st);
+      r16_for_mask<I + 1>(mask, res, init, a, grid, lds, st);
     }
   } else if (!init) {
     fail(FFP_ERR_ARG, "rows16: phase-skip mask %d is not built (FFP_R16_DBG)", mask);
@@ -366,11 +429,17 @@ template <int I = 0> void r16_for_mask(int mask, bool init, const ConvArgs* a, u
 }
 }  // namespace
 
-void conv_rows16_init() { r16_for_mask<>(0, true, nullptr, 0, nullptr); }
+void conv_rows16_init() { r16_for_mask<>(0, false, true, nullptr, 0, 0, nullptr); }
+
+// the weight-resident form: force_shape 23, or every eligible layer with FFP_ROWS16_RES=1 (A/B aid)
+static bool rows16_resident(const ConvArgs& a) {
+  static const bool env_on = [] { const char* e = getenv("FFP_ROWS16_RES"); return e && e[0] == '1'; }();
+  return (a.force_shape == 23 || (a.force_shape < 0 && env_on)) && (a.cin >> 5) <= R16Geo::RES_MAXC;
+}
 
 bool conv_rows16_eligible(const ConvOp& op, const ConvArgs& a) {
   const PackedConv& pc = *op.pc;
-  if (a.force_shape >= 0 && a.force_shape != 9) return false;   // tuning: another kernel was asked for
+  if (a.force_shape >= 0 && a.force_shape != 9 && a.force_shape != 23) return false;   // tuning: another kernel was asked for
   return pc.w16.p != nullptr && pc.dt == F16 && pc.k == 3 && op.stride == 1 && pc.cin % 32 == 0 && pc.cin >= 64 && pc.cout % 32 == 0 &&
          pc.cout <= 128 && a.fast_out && op.out.cs % 8 == 0 && op.out.coff % 8 == 0;
 }
@@ -389,10 +458,11 @@ void launch_conv_rows16(ConvArgs& a, const PackedConv& pc, Level* out_lvl, hipSt
   const long long items = (long long)n_tiles * a.n_nblk;
   long long per_xcd = (items + 7) / 8;
   per_xcd = (per_xcd + a.n_nblk - 1) / a.n_nblk * a.n_nblk;
-  long long ws = std::max<long long>(64, (per_xcd + G::TCAP - 1) / G::TCAP);
+  const bool res = rows16_resident(a);
+  long long ws = std::max<long long>(res ? 32 : 64, (per_xcd + G::TCAP - 1) / G::TCAP);          // resident weights: one workgroup per CU
   ws = (ws + a.n_nblk - 1) / a.n_nblk * a.n_nblk;
   FFP_CHECK(8 * ws < (1ll << 31) && (per_xcd + ws - 1) / ws <= G::TCAP, FFP_ERR_STATE, "rows16: launch geometry");
-  r16_for_mask<>(a.dbg, false, &a, (unsigned)(8 * ws), st);
+  r16_for_mask<>(a.dbg, res, false, &a, (unsigned)(8 * ws), res ? G::res_lds(a.cin >> 5) : G::LDS, st);
 }
 
 }  // namespace ffp
