@@ -29,6 +29,9 @@
 #define FFP_R16_DBG 0          // 1: also build the phase-skip instantiations of the kernel (tools/rows16_phase_probe.py); compile-time masks, so
 #endif                         //    that what is left keeps the production kernel's instruction schedule
 
+#ifndef FFP_R16_PRIO
+#define FFP_R16_PRIO 0         // 1: s_setprio 1 over the MFMA stream of a chunk (A/B)
+#endif
 #ifndef FFP_R16_STAMP
 #define FFP_R16_STAMP 0        // 1: diagnostic build — s_memtime stamps around the phases of every chunk, sums printed by the first workgroups
 #endif                         //    (MI355X guide, "In-kernel stamps"); never in a shipped build, the stamps cost ~10 % of the kernel
@@ -251,6 +254,9 @@ __global__ void __launch_bounds__(256, (RES ? 1 : 2)) conv_rows16_kernel(const C
     ldA(0, 0);
     ldA(1, 1);
     __builtin_amdgcn_sched_barrier(0);
+#if FFP_R16_PRIO
+    __builtin_amdgcn_s_setprio(1);                             // the MFMA stream outranks the partner wave's epilogue / set-up VALU work
+#endif
 #if FFP_R16_STAMP
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     st_t1 = __builtin_amdgcn_s_memtime();
@@ -283,6 +289,9 @@ __global__ void __launch_bounds__(256, (RES ? 1 : 2)) conv_rows16_kernel(const C
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+#if FFP_R16_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     advance_pf();
   };
 
