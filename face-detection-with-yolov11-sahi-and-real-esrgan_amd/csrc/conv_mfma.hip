@@ -961,6 +961,7 @@ void conv_kernels_init() {
   if (done) return;
   conv_rows_init();
   conv_rows16_init();
+  conv_rows16pc_init();
   conv_pw_init();
   conv_k3d_init();
   Family<float, 1, 1>::init(); Family<float, 3, 1>::init(); Family<float, 3, 2>::init();
@@ -1052,14 +1053,19 @@ bool conv_pw_enabled() {
 
 static bool use_rows16(const ConvOp& op, const ConvArgs& a) {
   if (!conv_rows16_eligible(op, a)) return false;
-  return a.force_shape == 9 || a.force_shape == 23 || (a.force_shape < 0 && conv_rows16_enabled());
+  return a.force_shape == 9 || a.force_shape == 23 || a.force_shape == 24 || (a.force_shape < 0 && conv_rows16_enabled());
 }
 
 void launch_conv(const ConvOp& op, hipStream_t st) {
   const PackedConv& pc = *op.pc;
   if (conv_direct_eligible(op)) { launch_conv_direct(op, st); return; }
   ConvArgs a = make_conv_args(op);
-  if (use_rows16(op, a)) { launch_conv_rows16(a, pc, op.out.lvl, st); FFP_HIP(hipGetLastError()); return; }
+  if (use_rows16(op, a)) {
+    if (conv_rows16pc_selected(a)) launch_conv_rows16pc(a, pc, op.out.lvl, st);
+    else launch_conv_rows16(a, pc, op.out.lvl, st);
+    FFP_HIP(hipGetLastError());
+    return;
+  }
   if (conv_rows_eligible(op, a)) { launch_conv_rows(a, op.out.lvl, st); FFP_HIP(hipGetLastError()); return; }
   if (a.force_shape >= 10 && a.force_shape <= 16) {      // pointwise kernels (conv_pw.hip): only ever picked by measurement (conv_tune) or by hand
     FFP_CHECK(conv_pw_mask(op, a) & (1u << a.force_shape), FFP_ERR_ARG, "conv %s: pointwise shape %d cannot run this op", pc.name.c_str(), a.force_shape);
@@ -1124,7 +1130,7 @@ std::string conv_variant(const ConvOp& op) {
   const PackedConv& pc = *op.pc;
   if (conv_direct_eligible(op)) return std::string(pc.dt == F32 ? "f32" : "f16") + "_k3_direct";
   const ConvArgs a = make_conv_args(op);
-  if (use_rows16(op, a)) return "f16_k3s1_rows16";
+  if (use_rows16(op, a)) return conv_rows16pc_selected(a) ? "f16_k3s1_rows16pc" : "f16_k3s1_rows16";
   if (conv_rows_eligible(op, a)) return "f16_k3s1_rows";
   if (op.force_shape >= 10 && op.force_shape <= 16) {
     static const char* pw[7] = {"f32x3_k1s1_pw1x4", "f32x3_k1s1_pw2x2", "f32x3_k1s1_pw2x1", "f32x3_k1s1_pw1x4w", "f32x3_k1s1_pw2x2w", "f32x3_k1s1_pw2x1w", "f32x3_k1s1_pw1x4s"};

@@ -448,7 +448,7 @@ static bool rows16_resident(const ConvArgs& a) {
 
 bool conv_rows16_eligible(const ConvOp& op, const ConvArgs& a) {
   const PackedConv& pc = *op.pc;
-  if (a.force_shape >= 0 && a.force_shape != 9 && a.force_shape != 23) return false;   // tuning: another kernel was asked for
+  if (a.force_shape >= 0 && a.force_shape != 9 && a.force_shape != 23 && a.force_shape != 24) return false;   // tuning: another kernel was asked for
   return pc.w16.p != nullptr && pc.dt == F16 && pc.k == 3 && op.stride == 1 && pc.cin % 32 == 0 && pc.cin >= 64 && pc.cout % 32 == 0 &&
          pc.cout <= 128 && a.fast_out && op.out.cs % 8 == 0 && op.out.coff % 8 == 0;
 }

@@ -351,8 +351,8 @@ def test_conv_k3_direct_weight_kernels(gpu_lib, case):
 
 def test_conv_rows16_weight_resident_form_is_bit_identical(gpu_lib):
     """conv_rows16_kernel<., RES = true> (force_shape 23: one workgroup per CU, the channel block's weights loaded into LDS once per
-    workgroup instead of once per tile) against the streaming form (force_shape 9): same MFMAs in the same order -> identical bits;
-    and against the fp16 reference. Ragged sizes, many tiles per workgroup, residual / upsample epilogues, 1..6 chunks."""
+    workgroup instead of once per tile) and conv_rows16pc_kernel (force_shape 24: producer waves stage and store, consumer waves
+    multiply) against the streaming form (force_shape 9): same MFMAs in the same order -> identical bits; and against the fp16 reference. Ragged sizes, many tiles per workgroup, residual / upsample epilogues, 1..6 chunks."""
     rng = np.random.default_rng(20261004)
     cases = [(2, 41, 42, 64, 32, 2, 0, False), (1, 70, 33, 96, 32, 2, 0, True), (3, 16, 16, 128, 32, 2, 0, False), (2, 52, 33, 160, 32, 2, 0, True),
              (1, 96, 96, 192, 64, 0, 0, True), (2, 17, 16, 64, 64, 2, 1, False), (1, 1, 1, 64, 32, 2, 0, False), (40, 24, 24, 128, 32, 2, 0, False),
@@ -370,6 +370,9 @@ def test_conv_rows16_weight_resident_form_is_bit_identical(gpu_lib):
             gpu_lib.op_conv2d_shape(23)
             y23 = gpu_lib.op_conv2d(x, wt, b, **kw)
             assert np.array_equal(y9, y23), (n, h, w, cin, cout, int((y9 != y23).sum()))
+            gpu_lib.op_conv2d_shape(24)                       # producer / consumer waves (conv_rows16pc.hip)
+            y24 = gpu_lib.op_conv2d(x, wt, b, **kw)
+            assert np.array_equal(y9, y24), ("rows16pc", n, h, w, cin, cout, int((y9 != y24).sum()))
             np.testing.assert_allclose(y23, ref_conv(x, wt, b, 1, 1, act, up, res, 0.2, True), rtol=2e-3, atol=2e-3)
     finally:
         gpu_lib.op_conv2d_shape(-1)

@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def variant(sym: str):
+    if "conv_rows16pc_kernel" in sym:
+        return "f16_k3s1_rows16pc"
     if "conv_rows16_kernel" in sym:
         return "f16_k3s1_rows16"
     m = re.search(r"conv_pw_kernel<(\d+), *(\d+), *(\d+), *(\d+), *(true|false)(?:, *(true|false))?>", sym) or \
