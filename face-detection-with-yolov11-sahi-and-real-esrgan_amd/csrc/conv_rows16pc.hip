@@ -49,6 +49,7 @@ struct PCGeo {
   static constexpr int LDS = DESC + TCAP * 48;                // 114560
 };
 
+template <int NS>              // staging register sets of a producer wave = chunks in flight ahead of the one being written (even)
 __global__ void __launch_bounds__(512, 2) conv_rows16pc_kernel(const ConvArgs a) {
   using G = PCGeo;
   constexpr int NP = G::NP;
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(512, 2) conv_rows16pc_kernel(const ConvArgs a)
         isrc[i] = ok ? (unsigned)(((iy >> a.up) * Wi + (ix >> a.up)) * a.in_cs * 2 + sl * 16) : OOB;
       }
     };
-    uint4 ra[NP], rb[NP];
+    uint4 sets[NS][NP];
     auto piece_fetch = [&](int p, uint4& r) {
       if (p < 5) {
         r = bload(rs_in, isrc[p] != OOB ? isrc[p] + (unsigned)(pf_c * 64) : OOB);
@@ -227,26 +228,26 @@ __global__ void __launch_bounds__(512, 2) conv_rows16pc_kernel(const ConvArgs a)
       }
     };
 
-    // ---- prologue: chunk 0 into stage 0, chunks 1 and 2 in flight --------------------------------------------------------------------
+    // ---- prologue: chunks 0 .. NS-1 requested (set c holds chunk c mod NS), chunk 0 into stage 0, its set re-requested for chunk NS -------
     setup_pf(0);
-    fetch_all(ra);
-    fetch_all(rb);
 #pragma unroll
-    for (int p = 0; p < NP; ++p) piece_stash(smem, p, ra[p]);
-    fetch_all(ra);
+    for (int k = 0; k < NS; ++k) fetch_all(sets[k]);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) piece_stash(smem, p, sets[0][p]);
+    fetch_all(sets[0]);
     __syncthreads();
     int cc = 0, cj = 0;                                // the chunk the consumers multiply in this iteration
-    for (int q = 0; q < Q; q += 2) {
-      // iteration q: stage 0 is being multiplied; rb holds chunk q + 1 -> stage 1; the item that ended at the last barrier is stored
-      restage(smem + G::STAGE, rb);
-      if (cc == 0 && cj > 0) epilogue(cj - 1);
-      if (++cc == NC) { cc = 0; ++cj; }
-      __syncthreads();
-      if (q + 1 >= Q) break;
-      restage(smem, ra);
-      if (cc == 0 && cj > 0) epilogue(cj - 1);
-      if (++cc == NC) { cc = 0; ++cj; }
-      __syncthreads();
+    for (int q0 = 0; q0 < Q; q0 += NS) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        if (q0 + k >= Q) break;
+        // iteration q0 + k: stage k & 1 is being multiplied; set (k + 1) % NS holds chunk q0 + k + 1 -> the other stage; the item that
+        // ended at the last barrier is stored
+        restage(smem + ((k + 1) & 1) * G::STAGE, sets[(k + 1) % NS]);
+        if (cc == 0 && cj > 0) epilogue(cj - 1);
+        if (++cc == NC) { cc = 0; ++cj; }
+        __syncthreads();
+      }
     }
     epilogue(J - 1);                                   // the last item's sums were written before the last barrier
     return;
@@ -331,7 +332,8 @@ __global__ void __launch_bounds__(512, 2) conv_rows16pc_kernel(const ConvArgs a)
 }  // namespace
 
 void conv_rows16pc_init() {
-  FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows16pc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PCGeo::LDS));
+  FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows16pc_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PCGeo::LDS));
+  FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows16pc_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PCGeo::LDS));
 }
 
 // force_shape 24, or every eligible layer with FFP_ROWS16_PC=1 (A/B aid). NOT the default: measured 0.73-0.94x of conv_rows16_kernel
@@ -355,7 +357,9 @@ void launch_conv_rows16pc(ConvArgs& a, const PackedConv& pc, Level* out_lvl, hip
   long long ws = std::max<long long>(32, (per_xcd + G::TCAP - 1) / G::TCAP);          // 8 x 32 workgroups: one per CU
   ws = (ws + a.n_nblk - 1) / a.n_nblk * a.n_nblk;
   FFP_CHECK(8 * ws < (1ll << 31) && (per_xcd + ws - 1) / ws <= G::TCAP, FFP_ERR_STATE, "rows16pc: launch geometry");
-  hipLaunchKernelGGL(conv_rows16pc_kernel, dim3((unsigned)(8 * ws)), dim3(512), G::LDS, st, a);
+  static const int ns = [] { const char* e = getenv("FFP_ROWS16_PC_SETS"); return e ? atoi(e) : 2; }();       // 4 sets (five chunks ahead) measured SLOWER than 2: 0.68-0.85x vs 0.78-0.95x of conv_rows16_kernel
+  if (ns == 2) hipLaunchKernelGGL(conv_rows16pc_kernel<2>, dim3((unsigned)(8 * ws)), dim3(512), G::LDS, st, a);
+  else hipLaunchKernelGGL(conv_rows16pc_kernel<4>, dim3((unsigned)(8 * ws)), dim3(512), G::LDS, st, a);
 }
 
 }  // namespace ffp
