@@ -1,6 +1,8 @@
 // common.cpp — thread-local error string, level (ragged batch) tables.
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace ffp {
 
 static thread_local std::string g_last_error;
@@ -21,18 +23,23 @@ Level::~Level() {
   if (stage) (void)hipHostFree(stage);
 }
 
-void Level::build(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st) {
+void Level::build(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st, int align) {
   FFP_CHECK(hs.size() == ws.size() && !hs.empty(), FFP_ERR_ARG, "level: empty batch");
   FFP_CHECK(!capacity(), FFP_ERR_STATE, "level: build() on a capacity-mode level (use assign)");
+  FFP_CHECK(align >= 1, FFP_ERR_ARG, "level: pixel alignment %d", align);
   n = (int)hs.size();
   h = hs; w = ws;
   off.resize(n);
   total_px = 0;
+  real_px = 0;
+  px_align = align;
+  d_frag_img.release();
   std::vector<int4> tab(n);
   for (int i = 0; i < n; ++i) {
     FFP_CHECK(h[i] > 0 && w[i] > 0, FFP_ERR_ARG, "level: image %d has size %dx%d", i, w[i], h[i]);
     off[i] = total_px;
-    total_px += (int64_t)h[i] * w[i];
+    real_px += (int64_t)h[i] * w[i];
+    total_px += ((int64_t)h[i] * w[i] + align - 1) / align * align;
   }
   FFP_CHECK(total_px < (int64_t)1 << 31, FFP_ERR_ARG, "level: %lld pixels exceed the 2^31 table limit", (long long)total_px);
   for (int i = 0; i < n; ++i) tab[i] = make_int4((int)off[i], h[i], w[i], 0);
@@ -111,6 +118,20 @@ void Level::assign(const std::vector<int>& hs, const std::vector<int>& ws, hipSt
   FFP_HIP(hipMemcpyAsync(d_tab.p, tab, sizeof(int4) * n, hipMemcpyHostToDevice, st));
   size_t so = sizeof(int4) * (size_t)n;
   for (auto& kv : tiles) fill_tiles(kv.first, kv.second, st, &so);
+}
+
+const int* Level::frag_img() {
+  FFP_CHECK(!capacity() && px_align % 32 == 0, FFP_ERR_STATE, "level: frag_img() needs images aligned to 32 pixels");
+  if (!d_frag_img.p) {
+    std::vector<int> m((size_t)(total_px / 32));
+    for (int i = 0; i < n; ++i) {
+      const int64_t end = i + 1 < n ? off[i + 1] : total_px;
+      for (int64_t f = off[i] / 32; f < end / 32; ++f) m[(size_t)f] = i;
+    }
+    d_frag_img.alloc(sizeof(int) * std::max<size_t>(m.size(), 1));
+    FFP_HIP(hipMemcpy(d_frag_img.p, m.data(), sizeof(int) * m.size(), hipMemcpyHostToDevice));
+  }
+  return d_frag_img.as<int>();
 }
 
 long long Level::count_tiles(int th) const {

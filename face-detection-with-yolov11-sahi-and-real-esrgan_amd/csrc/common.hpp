@@ -118,11 +118,19 @@ struct Level {
   Level(const Level&) = delete;
   Level& operator=(const Level&) = delete;
   ~Level();
-  void build(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st);
+  // px_align > 1: every image starts at a multiple of px_align pixels (padding pixels behind an image belong to no image: kernels that
+  // walk the flat pixel array compute them like any pixel, nothing reads them; they are kept out of the max-|value| slots). With a
+  // multiple of 32 no 32-pixel fragment of the flat array straddles two images: what the per-image exponent slots of the scaled
+  // split need in the 1x1 kernels (frag_img()).
+  void build(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st, int px_align = 1);
+  int px_align = 1;
+  int64_t real_px = 0;            // pixels that belong to images (== total_px without padding)
+  DevBuf d_frag_img;              // int per 32-pixel fragment of the flat array: its image (px_align % 32 == 0)
+  const int* frag_img();         // built on first use (synchronous copy: call it before the plan is captured)
   void reserve(int cap_n, int64_t cap_px, int cap_tiles16, hipStream_t st);
   void assign(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st);   // asynchronous on st (pinned staging)
   bool capacity() const { return cap_t16 > 0; }
-  int64_t actual_px() const { return capacity() ? act_px : total_px; }
+  int64_t actual_px() const { return capacity() ? act_px : real_px; }
   int actual_n() const { return capacity() ? act_n : n; }
   // *n_launch: tiles to launch (capacity mode: the table capacity); *d_count: device count of real tiles (capacity mode) or nullptr
   const int4* tile_table(int th, int* n_launch, const int** d_count, hipStream_t st);
@@ -145,6 +153,7 @@ struct TView {
   // device slot holding the bit pattern of max |value| over the whole BUFFER this view belongs to (every producer of a slice
   // raises it with an atomic max; reset per inference): the tensor-wide exponent of the scaled fp16 hi/lo split (FFP_PREC_F32X3)
   unsigned* amax = nullptr;
+  int amax_n = 1;                 // 1: one slot for the buffer; lvl->n: one slot per image (results independent of the batch mates)
   TView slice(int c0, int c) const { TView v = *this; v.coff += c0; v.C = c; return v; }
 };
 

@@ -36,6 +36,11 @@ struct ConvArgs {
   const unsigned* amax_in2;
   unsigned* amax_out;
   const float* oscale;
+  // per-image exponent slots (TView::amax_n > 1): slot of image i = amax_*[i]; amax_img = 0: one slot per buffer (index 0 for every image).
+  // 3x3 kernels know the image of a tile; the 1x1 kernels look the image of a 32-pixel fragment of the flat pixel array up in frag_img
+  // (levels aligned to 32 pixels: no fragment straddles two images)
+  int amax_img;
+  const int* frag_img;
   int ntiles_host;          // tile-loop kernels (conv_rows16.hip): tiles of an exact-mode launch (the grid no longer says)
   const int* n_tiles_dev;   // capacity-mode levels (Level::reserve): the batch's tile count lives in device memory and the grid is
                             // sized for the capacity — workgroups past n_tiles * n_nblk exit; nullptr: the grid is exact
@@ -69,6 +74,15 @@ __device__ __forceinline__ void raise_amax(unsigned* slot, float mx) {
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   const unsigned b = __float_as_uint(mx);
   if ((threadIdx.x & 63) == 0 && b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
+}
+
+// bit pattern of max |value| of the conv's input for image `img` (both sources of a two-source 1x1)
+__device__ __forceinline__ unsigned amax_in_bits(const ConvArgs& a, int img) {
+  if (!a.amax_in) return 0u;
+  const int i = a.amax_img ? img : 0;
+  unsigned m = a.amax_in[i];
+  if (a.amax_in2) m = max(m, a.amax_in2[i]);
+  return m;
 }
 
 // activation scale of the split and its inverse from a max-|value| bit pattern: 2^(13 - e) puts the largest value in [2^13, 2^14)

@@ -117,8 +117,13 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
     return make_uint4(v[0], v[1], v[2], v[3]);
   };
 
-  float tscale = 1.f, tinv = 1.f;
-  if (a.amax_in) split_scales((unsigned)__builtin_amdgcn_readfirstlane((int)*a.amax_in), &tscale, &tinv);
+  // activation scale of the split: per buffer, or per image (= per item: an item is one tile of one image). The prefetch cursor's
+  // scale travels with the staging set its pieces were requested into (set_ts); the epilogue looks its item's inverse scale up again.
+  float pf_ts = 1.f;
+  auto item_scales = [&](int img, float* ts, float* ti) {
+    *ts = 1.f; *ti = 1.f;
+    if (a.amax_in) split_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_in_bits(a, img)), ts, ti);
+  };
 
   // ---- LDS image: record index of halo pixel (hy, hx) and the XOR term of its slot index ------------------------------------------------
   auto rec_of = [](int hy, int hx) { return S == 1 ? hy * RP + hx : hy * RP + (hx & 1) * G::PP + (hx >> 1); };
@@ -142,6 +147,8 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
   auto setup_pf = [&](int j) {
     const int4 t = desc[j * 3], it = desc[j * 3 + 1];
     const int oy0 = sgpr(t.y), ox0 = sgpr(t.z), Hi = sgpr(it.y), Wi = sgpr(it.z);
+    float ti_unused;
+    item_scales(sgpr(t.x), &pf_ts, &ti_unused);
     const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.in) + ((long long)sgpr(it.x) * a.in_cs + a.in_coff) * 4;
     rs_in = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(inb), 0, 0x7FFFFFF0, 0x00020000);
 #pragma unroll
@@ -154,6 +161,7 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
   };
   constexpr int NSET = G::NSET;
   uint4 set[NSET][NPW];
+  float set_ts[NSET];                                  // split scale of the item each set's pieces belong to
   // `after`: a value the request must wait for in program order — the split results of the piece whose registers it refills. Without it
   // hipcc hoists the load above the split and gives it registers of its own: two staging sets live instead of one (36 VGPRs at stride 2).
   auto piece_fetch = [&](int k, int i, unsigned after = 0u) {
@@ -163,8 +171,8 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
   };
   auto piece_stash = [&](unsigned char* sb, int k, int i) {
     uint2 hi, lo;
-    split_pair(__uint_as_float(set[k][i].x), __uint_as_float(set[k][i].y), tscale, hi.x, lo.x);
-    split_pair(__uint_as_float(set[k][i].z), __uint_as_float(set[k][i].w), tscale, hi.y, lo.y);
+    split_pair(__uint_as_float(set[k][i].x), __uint_as_float(set[k][i].y), set_ts[k], hi.x, lo.x);
+    split_pair(__uint_as_float(set[k][i].z), __uint_as_float(set[k][i].w), set_ts[k], hi.y, lo.y);
     unsigned d = idst[i];
     asm volatile("" : "+v"(d));                        // keeps d ^ 32 inside the loop: hoisted, the lo addresses cost a register per piece
     *reinterpret_cast<uint2*>(sb + idst[i]) = hi;
@@ -268,6 +276,7 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
       if (s == 8) {
 #pragma unroll
         for (int i = 0; i < NPW; ++i) piece_fetch(KS, i, tok[i]);
+        set_ts[KS] = pf_ts;                                        // the cursor's item (advance_pf comes after the burst)
       }
 #pragma unroll
       for (int ni = 0; ni < NIW; ++ni)
@@ -296,6 +305,10 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
   auto epilogue = [&](int j, unsigned char* scr) __attribute__((always_inline)) {
     const int4 t = desc[j * 3], ot = desc[j * 3 + 2];
     const int oy0 = sgpr(t.y), ox0 = sgpr(t.z), Ho = sgpr(ot.y), Wo = sgpr(ot.z);
+    const int img = sgpr(t.x);
+    float ts_unused, tinv;
+    item_scales(img, &ts_unused, &tinv);
+    float am = 0.f;                                    // largest |value| of this item's outputs
     const long long out_base = sgpr(ot.x);
     const unsigned char* r1b = a.res1 ? reinterpret_cast<const unsigned char*>(a.res1) + (out_base * a.r1_cs + a.r1_coff) * 4 : wb;
     const unsigned char* r2b = a.res2 ? reinterpret_cast<const unsigned char*>(a.res2) + (out_base * a.r2_cs + a.r2_coff) * 4 : wb;
@@ -356,7 +369,7 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
           }
           if (oks[it]) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) amax_run = fmaxf(amax_run, fabsf(v[q]));
+            for (int q = 0; q < 4; ++q) am = fmaxf(am, fabsf(v[q]));
           }
           u32x4 ov = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
           __builtin_amdgcn_raw_buffer_store_b128(ov, rs_o, oks[it] ? (rel[it] * a.out_cs + nt * 32 + ch0) * 4 : OOB, 0, 0);
@@ -364,6 +377,8 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (a.amax_img) { if (a.amax_out) raise_amax(a.amax_out + img, am); }
+    else amax_run = fmaxf(amax_run, am);
   };
 
   // ---- the chunk stream ----------------------------------------------------------------------------------------------------------------
@@ -372,15 +387,18 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
   setup_pf(0);
 #pragma unroll
   for (int i = 0; i < NPW; ++i) piece_fetch(0, i);
+  set_ts[0] = pf_ts;
   advance_pf();
 #pragma unroll
   for (int t = 0; t < AD; ++t) ldA(t, 0, t);
 #pragma unroll
   for (int i = 0; i < NPW; ++i) piece_fetch(0, i, piece_stash(smem, 0, i));
+  set_ts[0] = pf_ts;
   advance_pf();
   if constexpr (NSET == 2) {
 #pragma unroll
     for (int i = 0; i < NPW; ++i) piece_fetch(1, i);
+    set_ts[1] = pf_ts;
     advance_pf();
   }
   __syncthreads();
@@ -401,7 +419,7 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
     if (q + 1 >= Q) break;
     step_chunk(std::integral_constant<int, 1>{}, smem + G::STAGE, smem);
   }
-  if (a.amax_out) raise_amax(a.amax_out, amax_run);
+  if (a.amax_out && !a.amax_img) raise_amax(a.amax_out, amax_run);
 }
 
 template <int S, int WM, int WN, int MI, int NIW> struct K3Cfg {

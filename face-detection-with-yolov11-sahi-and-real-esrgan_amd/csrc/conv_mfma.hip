@@ -207,25 +207,38 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
     return make_uint4(v[0], v[1], v[2], v[3]);
   };
 
-  // scaled split: tensor-wide power of two of the activations (max |value| of the input buffer(s) -> [2^13, 2^14) in fp16)
+  // scaled split: power of two of the activations (max |value| of the input buffer(s) -> [2^13, 2^14) in fp16), per buffer or — with
+  // per-image exponent slots — per image: a 3x3 workgroup works on ONE image (its tile's), a 1x1 workgroup on FR 32-pixel fragments
+  // of the flat pixel array, each inside one image (levels aligned to 32 pixels), so the scale is a property of the fragment
   float tscale = 1.f, tinv = 1.f;
+  int img3 = 0;                                         // KS == 3: the tile's image
+  if constexpr (KS == 3) img3 = __builtin_amdgcn_readfirstlane(a.tiles[tile].x);
+  auto frag_image = [&](int f) {                        // KS == 1: image of fragment f of this workgroup's pixel block
+    if (!a.frag_img) return 0;
+    const int nf = (int)(a.total_px >> 5);
+    return a.frag_img[min((int)(in_base >> 5) + f, nf - 1)];
+  };
   if constexpr (SPLIT) {
-    if (a.amax_in) {
-      unsigned m = *a.amax_in;
-      if (a.amax_in2) m = max(m, *a.amax_in2);
-      split_scales((unsigned)__builtin_amdgcn_readfirstlane((int)m), &tscale, &tinv);
-    }
+    if (a.amax_in && KS == 3) split_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_in_bits(a, img3)), &tscale, &tinv);
+    if (a.amax_in && KS == 1 && !a.amax_img) split_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_in_bits(a, 0)), &tscale, &tinv);
   }
 
   // per-thread staging slots: which vector each of this thread's RI + RW registers carries (chunk independent part)
   unsigned isrc[RI];           // byte offset of the pixel record relative to the resource base (OOB: zero fill)
   int ivec[RI];                // vector index inside the chunk
+  float tsc[RI];               // split scale of the slot's pixel (per-image exponent slots: the scale of its fragment's image)
 #pragma unroll
   for (int i = 0; i < RI; ++i) {
     const int idx = tid + i * 256;
-    isrc[i] = OOB; ivec[i] = 0;
+    isrc[i] = OOB; ivec[i] = 0; tsc[i] = tscale;
     if (!STEM && idx < G::NVI) {
       const int hp = idx / VPP;
+      if constexpr (SPLIT && KS == 1) {
+        if (a.amax_img && a.amax_in) {
+          float ti;
+          split_scales(amax_in_bits(a, frag_image(hp >> 5)), &tsc[i], &ti);
+        }
+      }
       ivec[i] = idx % VPP;
       long long rel;
       bool ok;
@@ -295,8 +308,8 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
       if (idx < G::NVI) {
         if (SPLIT) {   // 4 floats -> 4 fp16 hi parts + 4 fp16 residuals, stored in the hi / lo halves of the pixel record
           uint2 hi, lo;
-          split_pair(__uint_as_float(qi[i].x), __uint_as_float(qi[i].y), tscale, hi.x, lo.x);
-          split_pair(__uint_as_float(qi[i].z), __uint_as_float(qi[i].w), tscale, hi.y, lo.y);
+          split_pair(__uint_as_float(qi[i].x), __uint_as_float(qi[i].y), tsc[i], hi.x, lo.x);
+          split_pair(__uint_as_float(qi[i].z), __uint_as_float(qi[i].w), tsc[i], hi.y, lo.y);
           unsigned char* rec = buf + (idx / VPP) * PS + (idx % VPP) * 8;
           *reinterpret_cast<uint2*>(rec) = hi;
           *reinterpret_cast<uint2*>(rec + KC * 2) = lo;
@@ -486,10 +499,30 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
       bias_l[ni][q] = bv.x; bias_l[ni][q + 1] = bv.y; bias_l[ni][q + 2] = bv.z; bias_l[ni][q + 3] = bv.w;
       float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
       if constexpr (SPLIT) { if (a.oscale) sv = *reinterpret_cast<const float4*>(a.oscale + chb + q); }
-      osc_l[ni][q] = sv.x * tinv; osc_l[ni][q + 1] = sv.y * tinv; osc_l[ni][q + 2] = sv.z * tinv; osc_l[ni][q + 3] = sv.w * tinv;
+      osc_l[ni][q] = sv.x; osc_l[ni][q + 1] = sv.y; osc_l[ni][q + 2] = sv.z; osc_l[ni][q + 3] = sv.w;
     }
   }
-  float amax_run = 0.f;                               // largest |value| this lane stores (raise_amax at the end)
+  // per pixel fragment of this wave: inverse activation scale, image (slot index) and the end of the image's real pixels (padding
+  // pixels behind an image are computed like any pixel but neither stored nor counted in the max-|value| slot)
+  float tinv_f[MI], amax_run[MI];
+  int img_f[MI];
+  long long real_end[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    tinv_f[mi] = tinv; amax_run[mi] = 0.f; img_f[mi] = KS == 3 ? img3 : 0; real_end[mi] = a.total_px;
+    if constexpr (SPLIT && KS == 1) {
+      if (a.amax_img) {
+        const int im = __builtin_amdgcn_readfirstlane(frag_image(wm * MI + mi));
+        img_f[mi] = im;
+        const int4 it = a.out_tab[im];
+        real_end[mi] = (long long)it.x + (long long)it.y * it.z;
+        if (a.amax_in) {
+          float ts;
+          split_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_in_bits(a, im)), &ts, &tinv_f[mi]);
+        }
+      }
+    }
+  }
 
   // One step = one (k-group, tap): MI pixel fragments + NIW weight fragments -> NIW x MI MFMAs. The fragments of step
   // s + PD are requested from LDS before the MFMAs of step s issue (explicit register ring, everything unrolled): with one
@@ -595,7 +628,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
           const int pp = it * PPI + lane / LPP, ch0 = (lane % LPP) * CPL;
           if (KS == 1) {
             gps[it] = out_base + f * 32 + pp;
-            oks[it] = gps[it] < a.total_px;
+            oks[it] = gps[it] < real_end[mi];
           } else {
             const int oy = oy0 + 2 * f + (pp >> 4), ox = ox0 + (pp & 15);
             oks[it] = oy < Ho && ox < Wo;
@@ -607,6 +640,9 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
           if (a.res1) r1v[it] = bload(rs_r1, oks[it] ? (rel_px * a.r1_cs + nt * 32 + ch0) * ES : OOB);      // uniform branch, branch-free lanes
           if (a.res2) r2v[it] = bload(rs_r2, oks[it] ? (rel_px * a.r2_cs + nt * 32 + ch0) * ES : OOB);
         }
+        float oscf[CPL];                                        // output scale of this lane's channels x the fragment's inverse activation scale
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) oscf[q] = osc_l[ni][q] * tinv_f[mi];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // previous tile's staging reads have landed in registers
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -627,7 +663,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
           }
 #pragma unroll
           for (int q = 0; q < CPL; ++q) {
-            if constexpr (SPLIT) v[q] = apply_act(fmaf(v[q], osc_l[ni][q], bias_l[ni][q]), a.act);
+            if constexpr (SPLIT) v[q] = apply_act(fmaf(v[q], oscf[q], bias_l[ni][q]), a.act);
             else v[q] = apply_act(v[q] + bias_l[ni][q], a.act);
           }
           if (a.res1) {
@@ -642,7 +678,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
           }
           if constexpr (SPLIT) {
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) amax_run = fmaxf(amax_run, fabsf(v[q]));
+            for (int q = 0; q < CPL; ++q) amax_run[mi] = fmaxf(amax_run[mi], fabsf(v[q]));
           }
           uint4 ov;
           GT* o = reinterpret_cast<GT*>(&ov);
@@ -652,7 +688,12 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
         }
       }
     }
-    if constexpr (SPLIT) { if (a.amax_out) raise_amax(a.amax_out, amax_run); }
+    if constexpr (SPLIT) {
+      if (a.amax_out) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) raise_amax(a.amax_out + (a.amax_img ? img_f[mi] : 0), amax_run[mi]);
+      }
+    }
     return;
   }
 
@@ -664,7 +705,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
     bool ok;
     if (KS == 1) {
       gp = out_base + f * 32 + p;
-      ok = gp < a.total_px;
+      ok = gp < real_end[mi];
     } else {
       const int oy = oy0 + 2 * f + (p >> 4), ox = ox0 + (p & 15);
       ok = oy < Ho && ox < Wo;
@@ -684,10 +725,10 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
         if constexpr (SPLIT) {
           float4 sv = make_float4(1.f, 1.f, 1.f, 1.f);
           if (a.oscale) sv = *reinterpret_cast<const float4*>(a.oscale + ch);
-          v[0] = fmaf(acc[ni][mi][4 * g + 0], sv.x * tinv, bv.x);
-          v[1] = fmaf(acc[ni][mi][4 * g + 1], sv.y * tinv, bv.y);
-          v[2] = fmaf(acc[ni][mi][4 * g + 2], sv.z * tinv, bv.z);
-          v[3] = fmaf(acc[ni][mi][4 * g + 3], sv.w * tinv, bv.w);
+          v[0] = fmaf(acc[ni][mi][4 * g + 0], sv.x * tinv_f[mi], bv.x);
+          v[1] = fmaf(acc[ni][mi][4 * g + 1], sv.y * tinv_f[mi], bv.y);
+          v[2] = fmaf(acc[ni][mi][4 * g + 2], sv.z * tinv_f[mi], bv.z);
+          v[3] = fmaf(acc[ni][mi][4 * g + 3], sv.w * tinv_f[mi], bv.w);
         } else {
           v[0] = acc[ni][mi][4 * g + 0] + bv.x;
           v[1] = acc[ni][mi][4 * g + 1] + bv.y;
@@ -715,7 +756,7 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
         }
         if constexpr (SPLIT) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) if (ch + j < a.cout) amax_run = fmaxf(amax_run, fabsf(v[j]));
+          for (int j = 0; j < 4; ++j) if (ch + j < a.cout) amax_run[mi] = fmaxf(amax_run[mi], fabsf(v[j]));
         }
         const size_t oidx = (size_t)gp * a.out_cs + a.out_coff + ch;
         if (a.out_f32) {
@@ -730,7 +771,12 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
       }
     }
   }
-  if constexpr (SPLIT) { if (a.amax_out) raise_amax(a.amax_out, amax_run); }
+  if constexpr (SPLIT) {
+    if (a.amax_out) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) raise_amax(a.amax_out + (a.amax_img ? img_f[mi] : 0), amax_run[mi]);
+    }
+  }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------
@@ -1025,6 +1071,13 @@ ConvArgs make_conv_args(const ConvOp& op) {
     FFP_CHECK(a.up_map != nullptr, FFP_ERR_STATE, "conv %s: x2-source map missing", pc.name.c_str());
   }
   a.amax_in = a.amax_in2 = nullptr; a.amax_out = nullptr; a.oscale = nullptr;
+  a.amax_img = 0; a.frag_img = nullptr;
+  if (pc.split && op.in.amax && op.in.amax_n > 1) {          // a slot per image (Plan::per_image_amax)
+    FFP_CHECK(op.in.amax_n == op.in.lvl->n && (!op.out.amax || op.out.amax_n == op.in.amax_n) && (!op.has_up2 || !op.up2.amax || op.up2.amax_n == op.in.amax_n), FFP_ERR_STATE,
+              "conv %s: per-image exponent slots of input / output / second source disagree", pc.name.c_str());
+    a.amax_img = 1;
+    if (pc.k == 1) a.frag_img = op.out.lvl->frag_img();
+  }
   if (pc.split) {
     a.oscale = pc.oscale.as<float>();
     a.amax_in = op.in.amax;

@@ -112,19 +112,17 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
     for (int i = tid; i < nv; i += NW * 64) reinterpret_cast<uint4*>(smem)[i] = src[i];
   }
 
+  // activation scale of the split: per buffer, or (per-image exponent slots) per 32-pixel fragment = per image, looked up for every
+  // pixel block this wave walks (block_scales below)
   float tscale = 1.f, tinv = 1.f;
-  if (a.amax_in) {
-    unsigned m = *a.amax_in;
-    if (UP && a.amax_in2) m = max(m, *a.amax_in2);
-    split_scales((unsigned)__builtin_amdgcn_readfirstlane((int)m), &tscale, &tinv);
-  }
+  if (a.amax_in && !a.amax_img) split_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_in_bits(a, 0)), &tscale, &tinv);
   float bias_n[NT], osc_n[NT];
   unsigned cbyte[NT];                          // byte offset of this lane's channel inside a pixel record (OOB: padded channel)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int c = (ntile0 + nt) * 32 + p;
     bias_n[nt] = a.bias[c];
-    osc_n[nt] = (a.oscale ? a.oscale[c] : 1.f) * tinv;
+    osc_n[nt] = a.oscale ? a.oscale[c] : 1.f;
     cbyte[nt] = c < a.cout ? (unsigned)c * 4u : PW_OOB;
   }
 
@@ -177,12 +175,12 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
       issue(q, sp_in, voff, pr);
     }
   };
-  auto split8 = [&](const uint4& r0, const uint4& r1, f16x8& hi, f16x8& lo) {
+  auto split8 = [&](const uint4& r0, const uint4& r1, float ts, f16x8& hi, f16x8& lo) {
     union { uint4 u; f16x8 h; } H, Lo;
-    split_pair(__uint_as_float(r0.x), __uint_as_float(r0.y), tscale, H.u.x, Lo.u.x);
-    split_pair(__uint_as_float(r0.z), __uint_as_float(r0.w), tscale, H.u.y, Lo.u.y);
-    split_pair(__uint_as_float(r1.x), __uint_as_float(r1.y), tscale, H.u.z, Lo.u.z);
-    split_pair(__uint_as_float(r1.z), __uint_as_float(r1.w), tscale, H.u.w, Lo.u.w);
+    split_pair(__uint_as_float(r0.x), __uint_as_float(r0.y), ts, H.u.x, Lo.u.x);
+    split_pair(__uint_as_float(r0.z), __uint_as_float(r0.w), ts, H.u.y, Lo.u.y);
+    split_pair(__uint_as_float(r1.x), __uint_as_float(r1.y), ts, H.u.z, Lo.u.z);
+    split_pair(__uint_as_float(r1.z), __uint_as_float(r1.w), ts, H.u.w, Lo.u.w);
     hi = H.h;
     lo = Lo.h;
   };
@@ -205,6 +203,22 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
   wq[0][1] = *reinterpret_cast<const uint4*>(wl0 + 1024);
   int it = 0;                                  // ST: chunks done so far; the current stage is it & 1
   for (; pb < PB; pb += nslots) {
+    // this block's fragments: scale, inverse scale, image (slot index) and the end of the image's real pixels
+    float ts_f[MI], ti_f[MI];
+    int im_f[MI];
+    long long rend_f[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      ts_f[mi] = tscale; ti_f[mi] = tinv; im_f[mi] = 0; rend_f[mi] = a.total_px;
+      if (a.amax_img) {
+        const int nf = (int)(a.total_px >> 5);
+        const int im = sgpr(a.frag_img[min((int)(((long long)pb * BPX) >> 5) + wave * MI + mi, nf - 1)]);
+        im_f[mi] = im;
+        const int4 it = a.out_tab[im];
+        rend_f[mi] = (long long)sgpr(it.x) + (long long)sgpr(it.y) * sgpr(it.z);
+        if (a.amax_in) split_scales((unsigned)sgpr((int)amax_in_bits(a, im)), &ts_f[mi], &ti_f[mi]);
+      }
+    }
     const Span rs_next = block_span(a.in, pb + nslots, a.in_cs, a.in_coff);
     if constexpr (UP) load_vup(pb + nslots, vup_next);
     f32x16 acc[MI][NT];
@@ -236,7 +250,7 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
           const int q = j / NT, nt = j % NT;
           if (nt == 0) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) split8(raw[r][mi][2 * q], raw[r][mi][2 * q + 1], ph[mi], pl[mi]);
+            for (int mi = 0; mi < MI; ++mi) split8(raw[r][mi][2 * q], raw[r][mi][2 * q + 1], ts_f[mi], ph[mi], pl[mi]);
             if (q == 1) {                                            // both halves of the line are in hi/lo form: refill the slot HERE
               __builtin_amdgcn_sched_barrier(0);                     // (left alone the scheduler sinks every refill to the end of the loop
               if constexpr (UP) {                                    // body, where the next iteration waits for the first one at once)
@@ -280,25 +294,31 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
     const auto rs_out = rsrc(block_span(a.out, pb, a.out_cs, a.out_coff));
     const bool silu = a.act == ACT_SILU;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MI; ++mi) {
+      float am = 0.f;
+      const long long px0 = (long long)pb * BPX + (wave * MI + mi) * 32 + 4 * hh;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const unsigned vo = vout[mi] + cbyte[nt];
+        const float osc = osc_n[nt] * ti_f[mi];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          float v = fmaf(acc[mi][nt][i], osc_n[nt], bias_n[nt]);
+          float v = fmaf(acc[mi][nt][i], osc, bias_n[nt]);
           if (silu) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-          amax_run = fmaxf(amax_run, fabsf(v));
+          if (px0 + 8 * (i >> 2) + (i & 3) < rend_f[mi] && cbyte[nt] != PW_OOB) am = fmaxf(am, fabsf(v));      // padding pixels / channels do not count
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, vo + (unsigned)(8 * (i >> 2) + (i & 3)) * ocs4, 0, 0);
         }
       }
+      if (a.amax_img) { if (a.amax_out) raise_amax(a.amax_out + im_f[mi], am); }
+      else amax_run = fmaxf(amax_run, am);
+    }
     rs_cur = rs_next;
     if constexpr (UP) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) vup_cur[mi] = vup_next[mi];
     }
   }
-  if (a.amax_out) raise_amax(a.amax_out, amax_run);
+  if (a.amax_out && !a.amax_img) raise_amax(a.amax_out, amax_run);
 }
 
 template <int NW, int MI, int NT, int RP> struct PwCfg {

@@ -52,7 +52,7 @@ void ConvProfile::collect() {
 
 Level* Plan::add_level(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st) {
   levels.emplace_back(new Level());
-  levels.back()->build(hs, ws, st);
+  levels.back()->build(hs, ws, st, px_align);
   return levels.back().get();
 }
 
@@ -86,10 +86,16 @@ void Plan::materialize(TView& v) {
 TView Plan::alloc_virtual(Level* l, int C, DType dt) {
   TView v;
   v.ptr = nullptr; v.dt = dt; v.cs = C; v.coff = 0; v.C = C; v.lvl = l;
-  if (!amax_slots.p) amax_slots.alloc(sizeof(unsigned) * AMAX_CAP);
-  FFP_CHECK((int)amax_init.size() < AMAX_CAP, FFP_ERR_STATE, "plan: more than %d buffers", AMAX_CAP);
+  const int ns = per_image_amax ? l->n : 1;               // slots of this buffer
+  if (!amax_slots.p) {
+    amax_cap_slots = (size_t)AMAX_CAP * ns;
+    amax_slots.alloc(sizeof(unsigned) * amax_cap_slots);
+  }
+  FFP_CHECK(amax_init.size() + ns <= amax_cap_slots, FFP_ERR_STATE, "plan: more than %d buffers", AMAX_CAP);
+  FFP_CHECK(!per_image_amax || l->px_align % 32 == 0, FFP_ERR_STATE, "plan: per-image exponent slots need levels aligned to 32 pixels");
   v.amax = amax_slots.as<unsigned>() + amax_init.size();
-  amax_init.push_back(0u);
+  v.amax_n = ns;
+  amax_init.insert(amax_init.end(), ns, 0u);
   return v;
 }
 
@@ -97,7 +103,7 @@ void Plan::set_amax_bound(const TView& v, float bound) {
   FFP_CHECK(v.amax && amax_slots.p, FFP_ERR_STATE, "plan: view has no max-|value| slot");
   unsigned b;
   std::memcpy(&b, &bound, 4);
-  amax_init[v.amax - amax_slots.as<unsigned>()] = b;
+  for (int i = 0; i < v.amax_n; ++i) amax_init[(v.amax - amax_slots.as<unsigned>()) + i] = b;
 }
 
 void Plan::add_amax_reset(hipStream_t st) {
@@ -120,7 +126,7 @@ void Plan::add_amax_reset(hipStream_t st) {
 void Plan::add_conv(const ConvOp& op) {
   Step s;
   ConvOp o = op;
-  o.flops = conv_flops_of(*op.pc, op.out.lvl->total_px);
+  o.flops = conv_flops_of(*op.pc, op.out.lvl->actual_px());
   s.is_conv = true;
   s.variant = conv_variant(o);
   s.name = op.pc->name;

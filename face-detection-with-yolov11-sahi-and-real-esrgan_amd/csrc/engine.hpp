@@ -50,6 +50,11 @@ struct Plan {
   size_t bytes = 0;
   // max-|value| slots, one per allocated buffer (TView::amax): reset to `amax_init` by the first step of the plan
   static constexpr int AMAX_CAP = 512;
+  // per_image_amax: a slot per (buffer, image) instead of one per buffer — an image's exponent of the scaled split then depends on that
+  // image alone, so its results do not depend on its batch mates (sharding-independent bits in FFP_PREC_F32X3). Needs px_align % 32 == 0.
+  bool per_image_amax = false;
+  int px_align = 1;                    // pixel alignment of the images of every level this plan adds (Level::build)
+  size_t amax_cap_slots = 0;
   DevBuf amax_slots, amax_init_dev;
   std::vector<unsigned> amax_init;
   void set_amax_bound(const TView& v, float bound);      // a bound known without looking at data (image inputs, stem output)

@@ -58,7 +58,7 @@ void launch_dwconv(const DwConvOp& op, hipStream_t st);      // raises op.out.am
 // slots[i] = init[i] (bit patterns of max-|value| bounds known without looking at data; 0 elsewhere): first step of a plan
 void launch_amax_init(unsigned* slots, const unsigned* init, int n, hipStream_t st);
 // *dst = max(*dst, *src): an op that only moves values (nearest upsample into a concat slice) hands its input's bound on
-void launch_amax_max(unsigned* dst, const unsigned* src, hipStream_t st);
+void launch_amax_max(unsigned* dst, const unsigned* src, hipStream_t st, int n = 1);       // n slots (per-image slots: TView::amax_n)
 
 // SPPF: y1,y2,y3 = 5x5/9x9/13x13 stride-1 max pools of `in` (== three chained MaxPool2d(5,1,2)), written to three slices.
 void launch_sppf_pool(const TView& in, const TView& y1, const TView& y2, const TView& y3, hipStream_t st);

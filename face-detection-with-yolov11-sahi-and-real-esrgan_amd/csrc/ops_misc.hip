@@ -545,14 +545,17 @@ template <typename T, int RB>
 __global__ void __launch_bounds__(256) dwconv3x3_col_kernel(const T* __restrict__ in, int in_cs, int in_coff, int grp, int grp_stride, int grp_off,
                                                             T* __restrict__ out, int out_cs, int out_coff, const float* __restrict__ w /*[9][C]*/,
                                                             const float* __restrict__ bias, const T* __restrict__ res, int r_cs, int r_coff, int C, int act,
-                                                            const int4* __restrict__ tab, const int4* __restrict__ tiles, int n_tiles, unsigned* __restrict__ amax) {
+                                                            const int4* __restrict__ tab, const int4* __restrict__ tiles, int n_tiles, unsigned* __restrict__ amax,
+                                                            int amax_img /* 1: a slot per image (TView::amax_n > 1) */) {
   const int C4 = C >> 2;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   float mx = 0.f;
+  int img = 0;
   if (idx < (long long)n_tiles * 4 * C4) {
     const int c = (int)(idx % C4) * 4;
     const int strip = (int)((idx / C4) & 3);
     const int4 tl = tiles[idx / (4 * C4)];
+    img = amax_img ? tl.x : 0;
     const int4 t = tab[tl.x];
     const int Hh = t.y, Ww = t.z, x0 = tl.z + 4 * strip, y0 = tl.y;
     if (x0 < Ww) {
@@ -605,10 +608,16 @@ __global__ void __launch_bounds__(256) dwconv3x3_col_kernel(const T* __restrict_
     }
   }
   if (amax) {
+    const int i0 = __builtin_amdgcn_readfirstlane(img);
+    if (__all(img == i0)) {                              // the wave's threads share an image (the common case): one atomic per wave
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    const unsigned bb = __float_as_uint(mx);
-    if ((threadIdx.x & 63) == 0 && bb > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, bb);
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      const unsigned bb = __float_as_uint(mx);
+      if ((threadIdx.x & 63) == 0 && bb > __hip_atomic_load(amax + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax + i0, bb);
+    } else {
+      const unsigned bb = __float_as_uint(mx);
+      if (bb > __hip_atomic_load(amax + img, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax + img, bb);
+    }
   }
 }
 
@@ -675,7 +684,8 @@ void launch_dwconv(const DwConvOp& op, hipStream_t st) {
             FFP_ERR_ARG, "dwconv %s: channel counts/offsets must be multiples of 4", pc.name.c_str());
   const int4* tab = op.out.lvl->d_tab.as<int4>();
   static const bool col_walk = [] { const char* e = getenv("FFP_DW_STRIP"); return !(e && e[0] == '1'); }();      // FFP_DW_STRIP=1: the strip kernel (A/B aid)
-  if (col_walk && !op.out.lvl->capacity()) {
+  const int amax_img = op.out.amax && op.out.amax_n > 1 ? 1 : 0;
+  if ((col_walk || amax_img) && !op.out.lvl->capacity()) {
     constexpr int RB = 8;
     int n_tiles = 0;
     const int* d_count = nullptr;
@@ -685,14 +695,15 @@ void launch_dwconv(const DwConvOp& op, hipStream_t st) {
     if (op.in.dt == F32)
       hipLaunchKernelGGL((dwconv3x3_col_kernel<float, RB>), dim3(nbc), dim3(256), 0, st, (const float*)op.in.ptr, op.in.cs, op.in.coff, grp, gstride, op.grp_off,
                          (float*)op.out.ptr, op.out.cs, op.out.coff, pc.w.as<float>(), pc.bias.as<float>(), op.has_res ? (const float*)op.res.ptr : nullptr,
-                         op.res.cs, op.res.coff, C, op.act, tab, tiles, n_tiles, op.out.amax);
+                         op.res.cs, op.res.coff, C, op.act, tab, tiles, n_tiles, op.out.amax, amax_img);
     else
       hipLaunchKernelGGL((dwconv3x3_col_kernel<_Float16, RB>), dim3(nbc), dim3(256), 0, st, (const _Float16*)op.in.ptr, op.in.cs, op.in.coff, grp, gstride,
                          op.grp_off, (_Float16*)op.out.ptr, op.out.cs, op.out.coff, pc.w.as<float>(), pc.bias.as<float>(),
-                         op.has_res ? (const _Float16*)op.res.ptr : nullptr, op.res.cs, op.res.coff, C, op.act, tab, tiles, n_tiles, op.out.amax);
+                         op.has_res ? (const _Float16*)op.res.ptr : nullptr, op.res.cs, op.res.coff, C, op.act, tab, tiles, n_tiles, op.out.amax, amax_img);
     FFP_HIP(hipGetLastError());
     return;
   }
+  FFP_CHECK(!amax_img, FFP_ERR_STATE, "dwconv: per-image exponent slots need the tile-walking kernel (exact-mode level)");
   const unsigned nb = blocks_for(((op.out.lvl->total_px + 3) / 4) * (C / 4), 256);
   if (op.in.dt == F32)
     hipLaunchKernelGGL(dwconv3x3_strip_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)op.in.ptr, op.in.cs, op.in.coff, grp,
@@ -712,8 +723,9 @@ __global__ void amax_init_kernel(unsigned* __restrict__ slots, const unsigned* _
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) slots[i] = init[i];
 }
-__global__ void amax_max_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src) {
-  if (threadIdx.x == 0) *dst = max(*dst, *src);
+__global__ void amax_max_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = max(dst[i], src[i]);
 }
 }  // namespace
 
@@ -722,8 +734,8 @@ void launch_amax_init(unsigned* slots, const unsigned* init, int n, hipStream_t 
   FFP_HIP(hipGetLastError());
 }
 
-void launch_amax_max(unsigned* dst, const unsigned* src, hipStream_t st) {
-  hipLaunchKernelGGL(amax_max_kernel, dim3(1), dim3(64), 0, st, dst, src);
+void launch_amax_max(unsigned* dst, const unsigned* src, hipStream_t st, int n) {
+  hipLaunchKernelGGL(amax_max_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dst, src, n);
   FFP_HIP(hipGetLastError());
 }
 

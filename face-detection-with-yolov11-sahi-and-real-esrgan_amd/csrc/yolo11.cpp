@@ -76,6 +76,11 @@ const PackedConv* DetEngine::conv(const std::string& name) const {
 
 void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::vector<int>& ws) {
   const int n = (int)hs.size();
+  // scaled split: a max-|value| slot per (buffer, image), so that an item's bits do not depend on its batch mates (FFP_AMAX_PER_BUFFER=1:
+  // round 2's one slot per buffer, A/B aid); the 1x1 kernels find a fragment's image through Level::frag_img, hence the 32-pixel alignment
+  static const bool per_buffer = [] { const char* e = getenv("FFP_AMAX_PER_BUFFER"); return e && e[0] == '1'; }();
+  P.per_image_amax = split_ && !per_buffer;
+  P.px_align = P.per_image_amax ? 32 : 1;
   for (int l = 0; l < 6; ++l) {
     std::vector<int> h(n), w(n);
     for (int i = 0; i < n; ++i) { h[i] = hs[i] >> l; w[i] = ws[i] >> l; }
@@ -161,8 +166,8 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
     P.set_amax_bound(x0, std::max(o.pc->out_bound, 0.3f));
     if (direct && stem_conv_eligible(o, m1)) {
       // fp32-split YOLO11s: model.0 runs inside model.1's loader on the matrix cores; x0 is never stored
-      o.flops = conv_flops_of(*o.pc, x0.lvl->total_px);
-      m1.flops = conv_flops_of(*m1.pc, x1.lvl->total_px);
+      o.flops = conv_flops_of(*o.pc, x0.lvl->actual_px());
+      m1.flops = conv_flops_of(*m1.pc, x1.lvl->actual_px());
       P.stem = o; P.fused_stem = true;
       P.stemconv = m1; P.fused_stem_conv = true;
       P.stemconv_variant = "f32x3_k3s2_stem_fused";
@@ -173,7 +178,7 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
       P.materialize(x0);
       o.out = x0; m1.in = x0;
       if (direct) {
-        o.flops = conv_flops_of(*o.pc, x0.lvl->total_px);
+        o.flops = conv_flops_of(*o.pc, x0.lvl->actual_px());
         P.stem = o; P.fused_stem = true;
         P.conv_flops += o.flops; P.conv_launches += 1;
       } else {
@@ -235,12 +240,12 @@ void DetEngine::build_plan(DetPlan& P, const std::vector<int>& hs, const std::ve
   const bool fold12 = fold_up && c1024 % 64 == 0, fold15 = fold_up && c512 % 64 == 0;
   if (!fold12) {
     const TView up = cat12.slice(0, c1024);
-    P.add([x10, up](hipStream_t s) { launch_upsample2x(x10, up, s); launch_amax_max(up.amax, x10.amax, s); });
+    P.add([x10, up](hipStream_t s) { launch_upsample2x(x10, up, s); launch_amax_max(up.amax, x10.amax, s, up.amax_n); });
   }
   c3k2("model.13", cat12, x13, c512, false, 0.5, fold12 ? &x10 : nullptr);
   if (!fold15) {
     const TView up = cat15.slice(0, c512);
-    P.add([x13, up](hipStream_t s) { launch_upsample2x(x13, up, s); launch_amax_max(up.amax, x13.amax, s); });
+    P.add([x13, up](hipStream_t s) { launch_upsample2x(x13, up, s); launch_amax_max(up.amax, x13.amax, s, up.amax_n); });
   }
   const int chs[3] = {c256, c512, c1024};
   const int nk = 3 * nkpt_;

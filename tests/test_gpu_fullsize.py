@@ -42,18 +42,24 @@ def test_4k_fused_equals_tilewise_and_sharded(ctx):
     per_b = det.infer_tiles(frame, tiles[half:], 512, 0.25, 0.7, 300)
     for x, y in zip(per, per_a + per_b):
         assert np.array_equal(x, y)          # exact-fp32 mode: every item's result is independent of what else is in the batch, bit for bit
-    # The default arithmetic (FFP_PREC_F32X3, scaled fp16 hi/lo split) takes ONE power-of-two scale per activation tensor from the
-    # largest |value| in the batch, so an item's low-order bits can depend on its batch mates: sharded == unsharded to rounding, not bitwise
+    # The default arithmetic (FFP_PREC_F32X3, scaled fp16 hi/lo split) takes its power-of-two activation scale per (tensor, IMAGE) since
+    # round 3 (a max-|value| slot per image, Plan::per_image_amax): an item's bits no longer depend on its batch mates, so sharded ==
+    # unsharded bit for bit in this arithmetic too — whatever the split: halves, thirds, one item at a time
     lib3 = lib.Detector(ctx[1], arch="s", precision=lib.PREC_F32X3)
     q = lib3.infer_tiles(frame, tiles, 512, 0.25, 0.7, 300)
     qa = lib3.infer_tiles(frame, tiles[:half], 512, 0.25, 0.7, 300) + lib3.infer_tiles(frame, tiles[half:], 512, 0.25, 0.7, 300)
-    for x, y, z in zip(q, qa, per):
-        assert x.shape == y.shape == z.shape
+    third = len(tiles) // 3
+    qb = lib3.infer_tiles(frame, tiles[:third], 512, 0.25, 0.7, 300) + lib3.infer_tiles(frame, tiles[third:2 * third + 5], 512, 0.25, 0.7, 300) + \
+        lib3.infer_tiles(frame, tiles[2 * third + 5:], 512, 0.25, 0.7, 300)
+    for k, (x, y, y3, z) in enumerate(zip(q, qa, qb, per)):
+        assert np.array_equal(x, y) and np.array_equal(x, y3), k
         if x.shape[0]:
-            jy = [m[1] for m in match_by_iou(x[:, :4], y[:, :4], x[:, 4], y[:, 4])]
-            np.testing.assert_allclose(x[:, :5], y[jy, :5], atol=2e-3, rtol=1e-5)      # boxes in px, scores
+            assert x.shape == z.shape
             jz = [m[1] for m in match_by_iou(x[:, :4], z[:, :4], x[:, 4], z[:, 4])]
             np.testing.assert_allclose(x[:, :4], z[jz, :4], atol=5e-3, rtol=1e-5)      # and the split agrees with exact fp32
+    for k in (0, 31, 60):                                                              # single items, incl. the full-frame pass (padded deepest level)
+        one = lib3.infer_tiles(frame, [tiles[k]], 512, 0.25, 0.7, 300)[0]
+        assert np.array_equal(one, q[k]), k
     rows = []
     for t, d in zip(tiles, per):
         d = d.copy()
