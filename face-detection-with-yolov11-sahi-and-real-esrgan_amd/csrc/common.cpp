@@ -123,12 +123,16 @@ void Level::assign(const std::vector<int>& hs, const std::vector<int>& ws, hipSt
 const int* Level::frag_img() {
   FFP_CHECK(!capacity() && px_align % 32 == 0, FFP_ERR_STATE, "level: frag_img() needs images aligned to 32 pixels");
   if (!d_frag_img.p) {
-    std::vector<int> m((size_t)(total_px / 32));
+    FFP_CHECK(total_px < (1ll << 31), FFP_ERR_ARG, "level: frag_img() needs fewer than 2^31 pixels");
+    std::vector<int> m((size_t)(total_px / 32) * 2);
     for (int i = 0; i < n; ++i) {
       const int64_t end = i + 1 < n ? off[i + 1] : total_px;
-      for (int64_t f = off[i] / 32; f < end / 32; ++f) m[(size_t)f] = i;
+      for (int64_t f = off[i] / 32; f < end / 32; ++f) {
+        m[(size_t)f * 2] = i;
+        m[(size_t)f * 2 + 1] = (int)(off[i] + (int64_t)h[i] * w[i]);        // end of the image's real pixels
+      }
     }
-    d_frag_img.alloc(sizeof(int) * std::max<size_t>(m.size(), 1));
+    d_frag_img.alloc(sizeof(int) * std::max<size_t>(m.size(), 2));
     FFP_HIP(hipMemcpy(d_frag_img.p, m.data(), sizeof(int) * m.size(), hipMemcpyHostToDevice));
   }
   return d_frag_img.as<int>();

@@ -125,7 +125,7 @@ struct Level {
   void build(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st, int px_align = 1);
   int px_align = 1;
   int64_t real_px = 0;            // pixels that belong to images (== total_px without padding)
-  DevBuf d_frag_img;              // int per 32-pixel fragment of the flat array: its image (px_align % 32 == 0)
+  DevBuf d_frag_img;              // {image, end of its real pixels} per 32-pixel fragment of the flat array (px_align % 32 == 0)
   const int* frag_img();         // built on first use (synchronous copy: call it before the plan is captured)
   void reserve(int cap_n, int64_t cap_px, int cap_tiles16, hipStream_t st);
   void assign(const std::vector<int>& hs, const std::vector<int>& ws, hipStream_t st);   // asynchronous on st (pinned staging)

@@ -40,7 +40,7 @@ struct ConvArgs {
   // 3x3 kernels know the image of a tile; the 1x1 kernels look the image of a 32-pixel fragment of the flat pixel array up in frag_img
   // (levels aligned to 32 pixels: no fragment straddles two images)
   int amax_img;
-  const int* frag_img;
+  const int* frag_img;                 // [fragment] x {image, end of the image's real pixels}
   int ntiles_host;          // tile-loop kernels (conv_rows16.hip): tiles of an exact-mode launch (the grid no longer says)
   const int* n_tiles_dev;   // capacity-mode levels (Level::reserve): the batch's tile count lives in device memory and the grid is
                             // sized for the capacity — workgroups past n_tiles * n_nblk exit; nullptr: the grid is exact
@@ -68,12 +68,40 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
-// raise a max-|value| slot (see TView::amax): wave-wide maximum first, and the atomic only when it would change the slot
+// wave-uniform 32-bit load through the scalar cache: read-only tables and max-|value| slots written by EARLIER kernels. (Inside a
+// loop with stores hipcc turns a uniform global load into a vector load + readfirstlane, i.e. a full memory round trip on the
+// critical path; the constant address space keeps it an s_load whose result nothing waits for until it is used.)
+__device__ __forceinline__ int sload(const void* p, int idx) {
+  typedef const __attribute__((address_space(4))) int* cptr;
+  return reinterpret_cast<cptr>(reinterpret_cast<unsigned long long>(p))[idx];
+}
+
+// wave-wide maximum of non-negative, non-NaN floats as a wave-uniform bit pattern: four DPP steps inside the rows of 16 lanes,
+// then the four rows by v_readlane (no LDS round trips, unlike __shfl_xor)
+__device__ __forceinline__ unsigned wave_max_bits(float mx) {
+  int v = __float_as_int(mx);
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));    // row_half_mirror
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));    // row_mirror
+  const int a = max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16));
+  const int b = max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48));
+  return (unsigned)max(a, b);
+}
+
+// raise a max-|value| slot (see TView::amax): wave-wide maximum first, and the atomic only when it would change the slot.
+// `old` = a value the slot held at some earlier time (slots only grow, so a stale value costs at most a redundant atomic): kernels that
+// raise a slot per work item load it early so that nothing waits for the round trip here.
+__device__ __forceinline__ unsigned slot_peek(const unsigned* slot) {
+  return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void raise_amax(unsigned* slot, float mx, unsigned old) {
+  const unsigned b = wave_max_bits(mx);
+  if ((threadIdx.x & 63) == 0 && b > old) atomicMax(slot, b);
+}
 __device__ __forceinline__ void raise_amax(unsigned* slot, float mx) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  const unsigned b = __float_as_uint(mx);
-  if ((threadIdx.x & 63) == 0 && b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
+  const unsigned b = wave_max_bits(mx);
+  if ((threadIdx.x & 63) == 0 && b > slot_peek(slot)) atomicMax(slot, b);
 }
 
 // bit pattern of max |value| of the conv's input for image `img` (both sources of a two-source 1x1)
@@ -82,6 +110,14 @@ __device__ __forceinline__ unsigned amax_in_bits(const ConvArgs& a, int img) {
   const int i = a.amax_img ? img : 0;
   unsigned m = a.amax_in[i];
   if (a.amax_in2) m = max(m, a.amax_in2[i]);
+  return m;
+}
+// the same through the scalar cache (img wave-uniform)
+__device__ __forceinline__ unsigned amax_in_bits_s(const ConvArgs& a, int img) {
+  if (!a.amax_in) return 0u;
+  const int i = a.amax_img ? img : 0;
+  unsigned m = (unsigned)sload(a.amax_in, i);
+  if (a.amax_in2) m = max(m, (unsigned)sload(a.amax_in2, i));
   return m;
 }
 

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
   float pf_ts = 1.f;
   auto item_scales = [&](int img, float* ts, float* ti) {
     *ts = 1.f; *ti = 1.f;
-    if (a.amax_in) split_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_in_bits(a, img)), ts, ti);
+    if (a.amax_in) split_scales(amax_in_bits_s(a, img), ts, ti);                    // scalar cache: nothing waits for it before its first use
   };
 
   // ---- LDS image: record index of halo pixel (hy, hx) and the XOR term of its slot index ------------------------------------------------
@@ -309,6 +309,8 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
     float ts_unused, tinv;
     item_scales(img, &ts_unused, &tinv);
     float am = 0.f;                                    // largest |value| of this item's outputs
+    unsigned slot_now = 0u;                            // what the item's slot holds (read here, compared after the stores)
+    if (a.amax_img && a.amax_out) slot_now = slot_peek(a.amax_out + img);
     const long long out_base = sgpr(ot.x);
     const unsigned char* r1b = a.res1 ? reinterpret_cast<const unsigned char*>(a.res1) + (out_base * a.r1_cs + a.r1_coff) * 4 : wb;
     const unsigned char* r2b = a.res2 ? reinterpret_cast<const unsigned char*>(a.res2) + (out_base * a.r2_cs + a.r2_coff) * 4 : wb;
@@ -377,7 +379,7 @@ __global__ void __launch_bounds__(256, (K3Geo<S, WM, WN, MI, NIW>::OCC)) conv_k3
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (a.amax_img) { if (a.amax_out) raise_amax(a.amax_out + img, am); }
+    if (a.amax_img) { if (a.amax_out) raise_amax(a.amax_out + img, am, slot_now); }
     else amax_run = fmaxf(amax_run, am);
   };
 

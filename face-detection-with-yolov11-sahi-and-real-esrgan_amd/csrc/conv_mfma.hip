@@ -213,14 +213,29 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
   float tscale = 1.f, tinv = 1.f;
   int img3 = 0;                                         // KS == 3: the tile's image
   if constexpr (KS == 3) img3 = __builtin_amdgcn_readfirstlane(a.tiles[tile].x);
-  auto frag_image = [&](int f) {                        // KS == 1: image of fragment f of this workgroup's pixel block
-    if (!a.frag_img) return 0;
-    const int nf = (int)(a.total_px >> 5);
-    return a.frag_img[min((int)(in_base >> 5) + f, nf - 1)];
-  };
+  // KS == 1: {image, end of its real pixels, scale, inverse scale} of the FR fragments of this workgroup's pixel block, wave-uniform, read
+  // through the scalar cache (the table entries of a block are consecutive)
+  int f_img[G::FR], f_end[G::FR];
+  float f_ts[G::FR], f_ti[G::FR];
+#pragma unroll
+  for (int f = 0; f < G::FR; ++f) { f_img[f] = 0; f_end[f] = 0; f_ts[f] = 1.f; f_ti[f] = 1.f; }
   if constexpr (SPLIT) {
-    if (a.amax_in && KS == 3) split_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_in_bits(a, img3)), &tscale, &tinv);
-    if (a.amax_in && KS == 1 && !a.amax_img) split_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_in_bits(a, 0)), &tscale, &tinv);
+    if (a.amax_in && KS == 3) split_scales(amax_in_bits_s(a, img3), &tscale, &tinv);
+    if (a.amax_in && KS == 1 && !a.amax_img) split_scales(amax_in_bits_s(a, 0), &tscale, &tinv);
+    if constexpr (KS == 1) {
+      if (a.amax_img) {
+        const int nf = (int)(a.total_px >> 5), fb = __builtin_amdgcn_readfirstlane((int)(in_base >> 5));
+#pragma unroll
+        for (int f = 0; f < G::FR; ++f) {
+          const int e = 2 * min(fb + f, nf - 1);
+          f_img[f] = sload(a.frag_img, e);
+          f_end[f] = sload(a.frag_img, e + 1);
+        }
+#pragma unroll
+        for (int f = 0; f < G::FR; ++f)
+          if (a.amax_in) split_scales(amax_in_bits_s(a, f_img[f]), &f_ts[f], &f_ti[f]);
+      }
+    }
   }
 
   // per-thread staging slots: which vector each of this thread's RI + RW registers carries (chunk independent part)
@@ -235,8 +250,8 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
       const int hp = idx / VPP;
       if constexpr (SPLIT && KS == 1) {
         if (a.amax_img && a.amax_in) {
-          float ti;
-          split_scales(amax_in_bits(a, frag_image(hp >> 5)), &tsc[i], &ti);
+#pragma unroll
+          for (int f = 0; f < G::FR; ++f) if ((hp >> 5) == f) tsc[i] = f_ts[f];
         }
       }
       ivec[i] = idx % VPP;
@@ -512,14 +527,10 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
     tinv_f[mi] = tinv; amax_run[mi] = 0.f; img_f[mi] = KS == 3 ? img3 : 0; real_end[mi] = a.total_px;
     if constexpr (SPLIT && KS == 1) {
       if (a.amax_img) {
-        const int im = __builtin_amdgcn_readfirstlane(frag_image(wm * MI + mi));
-        img_f[mi] = im;
-        const int4 it = a.out_tab[im];
-        real_end[mi] = (long long)it.x + (long long)it.y * it.z;
-        if (a.amax_in) {
-          float ts;
-          split_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_in_bits(a, im)), &ts, &tinv_f[mi]);
-        }
+        const int fw = __builtin_amdgcn_readfirstlane(wm * MI + mi);
+#pragma unroll
+        for (int f = 0; f < G::FR; ++f)
+          if (fw == f) { img_f[mi] = f_img[f]; real_end[mi] = f_end[f]; tinv_f[mi] = f_ti[f]; }
       }
     }
   }
@@ -691,7 +702,12 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
     if constexpr (SPLIT) {
       if (a.amax_out) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) raise_amax(a.amax_out + (a.amax_img ? img_f[mi] : 0), amax_run[mi]);
+        for (int mi = 0; mi < MI; ++mi) {                 // fragments of one image (always, for a 3x3 tile) raise its slot once
+          bool same = false;
+          if (mi + 1 < MI) same = !a.amax_img || img_f[mi + 1] == img_f[mi];
+          if (same) amax_run[mi + 1 < MI ? mi + 1 : mi] = fmaxf(amax_run[mi + 1 < MI ? mi + 1 : mi], amax_run[mi]);
+          else raise_amax(a.amax_out + (a.amax_img ? img_f[mi] : 0), amax_run[mi]);
+        }
       }
     }
     return;
@@ -774,7 +790,12 @@ __global__ void __launch_bounds__(256, (Geo<T, KS, STRIDE, WM, WN, MI, NIW, KC>:
   if constexpr (SPLIT) {
     if (a.amax_out) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) raise_amax(a.amax_out + (a.amax_img ? img_f[mi] : 0), amax_run[mi]);
+      for (int mi = 0; mi < MI; ++mi) {
+        bool same = false;
+        if (mi + 1 < MI) same = !a.amax_img || img_f[mi + 1] == img_f[mi];
+        if (same) amax_run[mi + 1 < MI ? mi + 1 : mi] = fmaxf(amax_run[mi + 1 < MI ? mi + 1 : mi], amax_run[mi]);
+        else raise_amax(a.amax_out + (a.amax_img ? img_f[mi] : 0), amax_run[mi]);
+      }
     }
   }
 }

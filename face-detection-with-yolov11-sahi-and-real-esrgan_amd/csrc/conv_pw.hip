@@ -14,7 +14,8 @@
 //     weights are in. A ring of RP line-loads per pixel (RP x 128 B x MI x 32 px per wave, 8 waves per CU) stays in
 //     flight, across work items too — the next pixel block's first lines are requested before this block's epilogue;
 //   * the weights of the workgroup's channel block are LDS-resident for the life of the (persistent) workgroup: a block
-//     walks pixel blocks slot, slot + nslots, ... with the same weights;
+//     walks a CONTIGUOUS run of pixel blocks with the same weights (contiguous: a wave then meets every image once, and the
+//     per-image max-|value| slots cost one atomic per image and wave instead of one per block);
 //   * epilogue: lanes 0..31 of a store are 32 consecutive channels of one pixel — whole 128-byte lines from dword
 //     stores, no LDS transposition; pixel / channel tails are cut by the buffer range check, not by branches.
 #include <algorithm>
@@ -48,6 +49,9 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
   const int ntile0 = nblk * NT;
   const int ncg = a.ncg, npairs = ncg >> 1;
   const int PB = (int)((a.total_px + BPX - 1) / BPX);
+  const int pb_q = PB / nslots, pb_r = PB % nslots;                      // this slot's run of pixel blocks: [pb_begin, pb_end)
+  const int pb_begin = slot * pb_q + min(slot, pb_r), pb_end = pb_begin + pb_q + (slot < pb_r ? 1 : 0);
+  auto after = [&](int pb, int k) { return pb + k < pb_end ? pb + k : PB; };      // k blocks on, or PB = nothing (empty span)
 
   auto sgpr = [](unsigned long long u) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
@@ -99,7 +103,7 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
       copy_chunk(0, smem);
       __syncthreads();
       int it = 0;
-      for (int pbp = slot; pbp < PB; pbp += nslots)
+      for (int pbp = pb_begin; pbp < pb_end; ++pbp)
         for (int c = 0; c < nchunks; ++c, ++it) {
           copy_chunk(c + 1 < nchunks ? c + 1 : 0, smem + ((it + 1) & 1) * STAGE);
           __syncthreads();
@@ -113,7 +117,7 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
   }
 
   // activation scale of the split: per buffer, or (per-image exponent slots) per 32-pixel fragment = per image, looked up for every
-  // pixel block this wave walks (block_scales below)
+  // pixel block this wave walks (in the block loop below)
   float tscale = 1.f, tinv = 1.f;
   if (a.amax_in && !a.amax_img) split_scales((unsigned)__builtin_amdgcn_readfirstlane((int)amax_in_bits(a, 0)), &tscale, &tinv);
   float bias_n[NT], osc_n[NT];
@@ -185,7 +189,7 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
     lo = Lo.h;
   };
 
-  int pb = slot;
+  int pb = pb_begin;
   Span rs_cur = block_span(a.in, pb, a.in_cs, a.in_coff);
   if constexpr (UP) {
     sp_up.base = sgpr(reinterpret_cast<unsigned long long>(a.up_src));
@@ -196,13 +200,31 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
   for (int r = 0; r < RP; ++r) fetch(raw[r], rs_cur, vup_cur, r);
   __syncthreads();                             // weights visible; from here on the waves run on their own
 
-  float amax_run = 0.f;
+  // per-image exponent slots: {image, end of its real pixels} of this wave's fragments and the input's max-|value| bits, fetched through
+  // the scalar cache TWO blocks (table) / ONE block (slot) ahead, so that the chain table -> slot never sits on the critical path
+  const int nfrag = (int)(a.total_px >> 5);
+  auto frag_of = [&](int pbx, int mi) { return 2 * min((int)(((long long)pbx * BPX) >> 5) + wave * MI + mi, nfrag - 1); };
+  int im_n[MI], re_n[MI], im_nn[MI], re_nn[MI];
+  unsigned am_n[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    im_n[mi] = im_nn[mi] = 0; re_n[mi] = re_nn[mi] = 0; am_n[mi] = 0u;
+    if (a.amax_img) {
+      im_n[mi] = sload(a.frag_img, frag_of(pb, mi));
+      re_n[mi] = sload(a.frag_img, frag_of(pb, mi) + 1);
+      im_nn[mi] = sload(a.frag_img, frag_of(after(pb, 1), mi));
+      re_nn[mi] = sload(a.frag_img, frag_of(after(pb, 1), mi) + 1);
+      am_n[mi] = amax_in_bits_s(a, im_n[mi]);
+    }
+  }
   const unsigned char* wl0 = smem + lane * 16;
   uint4 wq[2][2];                              // weight fragment ring {hi, lo} x 2 steps
   wq[0][0] = *reinterpret_cast<const uint4*>(wl0);
   wq[0][1] = *reinterpret_cast<const uint4*>(wl0 + 1024);
   int it = 0;                                  // ST: chunks done so far; the current stage is it & 1
-  for (; pb < PB; pb += nslots) {
+  int run_img = -1;                            // the image this wave is collecting max |value| for, and the per-lane maximum so far
+  float run_max = 0.f;
+  for (; pb < pb_end; ++pb) {
     // this block's fragments: scale, inverse scale, image (slot index) and the end of the image's real pixels
     float ts_f[MI], ti_f[MI];
     int im_f[MI];
@@ -211,16 +233,18 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
     for (int mi = 0; mi < MI; ++mi) {
       ts_f[mi] = tscale; ti_f[mi] = tinv; im_f[mi] = 0; rend_f[mi] = a.total_px;
       if (a.amax_img) {
-        const int nf = (int)(a.total_px >> 5);
-        const int im = sgpr(a.frag_img[min((int)(((long long)pb * BPX) >> 5) + wave * MI + mi, nf - 1)]);
-        im_f[mi] = im;
-        const int4 it = a.out_tab[im];
-        rend_f[mi] = (long long)sgpr(it.x) + (long long)sgpr(it.y) * sgpr(it.z);
-        if (a.amax_in) split_scales((unsigned)sgpr((int)amax_in_bits(a, im)), &ts_f[mi], &ti_f[mi]);
+        im_f[mi] = im_n[mi];
+        rend_f[mi] = re_n[mi];
+        if (a.amax_in) split_scales(am_n[mi], &ts_f[mi], &ti_f[mi]);
+        im_n[mi] = im_nn[mi];
+        re_n[mi] = re_nn[mi];
+        am_n[mi] = amax_in_bits_s(a, im_n[mi]);
+        im_nn[mi] = sload(a.frag_img, frag_of(after(pb, 2), mi));
+        re_nn[mi] = sload(a.frag_img, frag_of(after(pb, 2), mi) + 1);
       }
     }
-    const Span rs_next = block_span(a.in, pb + nslots, a.in_cs, a.in_coff);
-    if constexpr (UP) load_vup(pb + nslots, vup_next);
+    const Span rs_next = block_span(a.in, after(pb, 1), a.in_cs, a.in_coff);
+    if constexpr (UP) load_vup(after(pb, 1), vup_next);
     f32x16 acc[MI][NT];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -309,8 +333,13 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, vo + (unsigned)(8 * (i >> 2) + (i & 3)) * ocs4, 0, 0);
         }
       }
-      if (a.amax_img) { if (a.amax_out) raise_amax(a.amax_out + im_f[mi], am); }
-      else amax_run = fmaxf(amax_run, am);
+      // the wave's fragments come in pixel order, so an image is one run of them: its slot is raised when the run ends
+      if (im_f[mi] != run_img) {
+        if (run_img >= 0 && a.amax_out) raise_amax(a.amax_out + run_img, run_max);
+        run_img = im_f[mi];
+        run_max = 0.f;
+      }
+      run_max = fmaxf(run_max, am);
     }
     rs_cur = rs_next;
     if constexpr (UP) {
@@ -318,7 +347,7 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
       for (int mi = 0; mi < MI; ++mi) vup_cur[mi] = vup_next[mi];
     }
   }
-  if (a.amax_out && !a.amax_img) raise_amax(a.amax_out, amax_run);
+  if (a.amax_out && run_img >= 0) raise_amax(a.amax_out + run_img, run_max);
 }
 
 template <int NW, int MI, int NT, int RP> struct PwCfg {
