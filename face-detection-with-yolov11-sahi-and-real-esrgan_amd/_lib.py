@@ -101,6 +101,7 @@ _SIGS = {
     "ffp_jpeg_info": (C.c_int, [_p(C.c_uint8), C.c_int64, _p(C.c_int32), _p(C.c_int32), _p(C.c_int32)]),
     "ffp_jpeg_decode": (C.c_int, [C.c_int, _p(C.c_uint8), C.c_int64, C.c_int, _p(C.c_uint8), C.c_int64]),
     "ffp_jpeg_decode_dev": (C.c_int, [C.c_int, _p(C.c_uint8), C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int64]),
+    "ffp_jpeg_decode_stats": (C.c_int, [_p(C.c_int64), _p(C.c_int64), _p(C.c_int64)]),
     "ffp_op_conv2d_shape": (C.c_int, [C.c_int]),
     "ffp_op_conv1x1_up2": (C.c_int, [C.c_int, C.c_int, _p(C.c_float), _p(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p(C.c_float),
                                      _p(C.c_float), C.c_int, C.c_int, _p(C.c_float)]),
@@ -511,6 +512,13 @@ def jpeg_decode_dev(data: bytes, d_ptr: int, row_stride: int, cap: int, bgr: boo
     buf = np.frombuffer(data, np.uint8)
     _check(lib().ffp_jpeg_decode_dev(device, buf.ctypes.data_as(_p(C.c_uint8)), len(buf), int(bgr), C.c_void_p(d_ptr), row_stride, cap))
     return h, w
+
+
+def jpeg_decode_stats():
+    """(files Huffman-decoded on the device, files that fell back to the host decoder, extra synchronisation rounds) since load"""
+    a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    _check(lib().ffp_jpeg_decode_stats(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
 
 
 def _ragged(rows, width, dtype):

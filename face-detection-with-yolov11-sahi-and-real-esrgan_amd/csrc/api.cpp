@@ -667,6 +667,16 @@ int ffp_jpeg_decode(int device, const uint8_t* data, int64_t n, int bgr, uint8_t
   FFP_API_END
 }
 
+int ffp_jpeg_decode_stats(int64_t* device_decodes, int64_t* host_fallbacks, int64_t* extra_sync_rounds) {
+  FFP_API_BEGIN
+  long long a = 0, b = 0, c = 0;
+  jpeg_huff_stats(&a, &b, &c);
+  if (device_decodes) *device_decodes = a;
+  if (host_fallbacks) *host_fallbacks = b;
+  if (extra_sync_rounds) *extra_sync_rounds = c;
+  FFP_API_END
+}
+
 static int g_op_conv_shape = -1;
 int ffp_op_conv2d_shape(int force_shape) {
   g_op_conv_shape = force_shape;

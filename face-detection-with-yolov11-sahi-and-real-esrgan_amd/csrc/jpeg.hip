@@ -15,6 +15,8 @@
 #include <mutex>
 #include <vector>
 
+#include <cstdlib>
+
 #include "jpeg.hpp"
 
 namespace ffp {
@@ -660,10 +662,16 @@ void JpegDecodeWs::ensure(const JpegScan& s) {
     const size_t nb = (size_t)s.comp[c].blocks_x * s.comp[c].blocks_y;
     if (nb > cap[c]) {
       cap[c] = nb * 5 / 4 + 64;
-      host[c].ensure(cap[c] * 64 * sizeof(short));
       dev[c] = DevBuf(cap[c] * 64 * sizeof(short));
       plane[c] = DevBuf(cap[c] * 64 + 16);
     }
+  }
+}
+
+void JpegDecodeWs::ensure_host(const JpegScan& s) {
+  ensure(s);
+  for (int c = 0; c < s.ncomp; ++c) {
+    host[c].ensure(cap[c] * 64 * sizeof(short));
     const_cast<JpegScan&>(s).coef[c] = static_cast<short*>(host[c].p);
   }
 }
@@ -701,12 +709,12 @@ void jpeg_ws_release(JpegDecodeWs* ws) {
   if (cur != owner) (void)hipSetDevice(cur);
 }
 
-void jpeg_reconstruct_device(const JpegScan& s, JpegDecodeWs& ws, unsigned char* d_out, long long stride, int bgr, hipStream_t st) {
+void jpeg_reconstruct_device(const JpegScan& s, JpegDecodeWs& ws, unsigned char* d_out, long long stride, int bgr, hipStream_t st, bool upload) {
   FFP_HIP(hipMemcpyAsync(ws.qt.p, s.qt, sizeof(unsigned short) * 64 * 4, hipMemcpyHostToDevice, st));
   for (int c = 0; c < s.ncomp; ++c) {
     const JpegComp& cp = s.comp[c];
     const int nb = cp.blocks_x * cp.blocks_y;
-    FFP_HIP(hipMemcpyAsync(ws.dev[c].p, s.coef[c], (size_t)nb * 64 * sizeof(short), hipMemcpyHostToDevice, st));
+    if (upload) FFP_HIP(hipMemcpyAsync(ws.dev[c].p, s.coef[c], (size_t)nb * 64 * sizeof(short), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nb + 7) / 8), dim3(64), 0, st, ws.dev[c].as<short>(), nb, cp.blocks_x, ws.qt.as<unsigned short>() + 64 * cp.tq,
                        ws.plane[c].as<unsigned char>());
   }
@@ -716,12 +724,18 @@ void jpeg_reconstruct_device(const JpegScan& s, JpegDecodeWs& ws, unsigned char*
                      s.ncomp == 3 ? ws.plane[1].as<unsigned char>() : nullptr, s.ncomp == 3 ? ws.plane[2].as<unsigned char>() : nullptr, s.h, s.w,
                      s.comp[0].blocks_x * 8, s.ncomp == 3 ? s.comp[1].blocks_x * 8 : 0, ch, cw, hsub, vsub, s.ncomp, bgr, stride, d_out);
   FFP_HIP(hipGetLastError());
-  FFP_HIP(hipStreamSynchronize(st));                   // the staging planes go back to the pool after this
+}
+
+// FFP_JPEG_HOST_HUFFMAN=1: entropy decoding on the host for every file (round-2 behaviour; A/B and the fallback's own tests)
+static bool host_huffman_forced() {
+  static const bool v = [] { const char* e = std::getenv("FFP_JPEG_HOST_HUFFMAN"); return e && e[0] == '1'; }();
+  return v;
 }
 
 void jpeg_decode_to_device(const unsigned char* data, long long n, unsigned char* d_out, long long stride, long long cap, int bgr, hipStream_t st, int* out_h, int* out_w) {
   JpegScan s;
-  jpeg_entropy_decode(data, n, s, true);
+  JpegHead head;
+  jpeg_entropy_decode(data, n, s, true, &head);
   if (out_h) *out_h = s.h;
   if (out_w) *out_w = s.w;
   if (stride == 0) stride = (long long)s.w * 3;
@@ -729,8 +743,26 @@ void jpeg_decode_to_device(const unsigned char* data, long long n, unsigned char
   JpegDecodeWs* ws = jpeg_ws_acquire();
   try {
     ws->ensure(s);
-    jpeg_entropy_decode(data, n, s, false);
-    jpeg_reconstruct_device(s, *ws, d_out, stride, bgr, st);
+    bool done = false;
+    if (!host_huffman_forced()) {
+      // the whole decode is queued in one go — entropy decoding (jpeg_huff.hip) and reconstruction — and checked after ONE synchronisation
+      jpeg_huff_decode_async(data, n, s, head, *ws, st);
+      jpeg_reconstruct_device(s, *ws, d_out, stride, bgr, st, false);
+      FFP_HIP(hipStreamSynchronize(st));
+      const int rc = jpeg_huff_finish(s, *ws, st);
+      if (rc == 2) {
+        jpeg_reconstruct_device(s, *ws, d_out, stride, bgr, st, false);
+        FFP_HIP(hipStreamSynchronize(st));
+      }
+      done = rc != 0;
+      if (!done) jpeg_huff_note_fallback();
+    }
+    if (!done) {                                 // the host decoder: libjpeg's behaviour on damaged streams, and its error reports
+      ws->ensure_host(s);
+      jpeg_entropy_decode(data, n, s, false);
+      jpeg_reconstruct_device(s, *ws, d_out, stride, bgr, st, true);
+      FFP_HIP(hipStreamSynchronize(st));         // the staging planes go back to the pool after this
+    }
   } catch (...) {
     jpeg_ws_release(ws);
     throw;

@@ -95,7 +95,7 @@ struct BitReader {
 
 }  // namespace
 
-void jpeg_entropy_decode(const unsigned char* d, long long n, JpegScan& out, bool header_only) {
+void jpeg_entropy_decode(const unsigned char* d, long long n, JpegScan& out, bool header_only, JpegHead* head) {
   FFP_CHECK(d && n > 4 && d[0] == 0xFF && d[1] == 0xD8, FFP_ERR_ARG, "jpeg: not a JPEG stream");
   HuffTab dc[4], ac[4];
   bool have_qt[4] = {false, false, false, false};
@@ -129,6 +129,13 @@ void jpeg_entropy_decode(const unsigned char* d, long long n, JpegScan& out, boo
         const int tc = s[k] >> 4, th = s[k] & 15;
         FFP_CHECK(tc < 2 && th < 4 && cnt <= 256 && k + 17 + cnt <= sl, FFP_ERR_ARG, "jpeg: bad Huffman table");
         (tc ? ac : dc)[th].build(s + k + 1, s + k + 17, cnt);
+        if (head) {                                          // the raw table, for the device decoder (jpeg_huff.hip)
+          JpegHuffSpec& hs = (tc ? head->ac : head->dc)[th];
+          hs.present = true;
+          hs.n = cnt;
+          std::memcpy(hs.bits, s + k + 1, 16);
+          std::memcpy(hs.vals, s + k + 17, cnt);
+        }
         k += 17 + cnt;
       }
     } else if (m == 0xC0 || m == 0xC1) {
@@ -176,6 +183,7 @@ void jpeg_entropy_decode(const unsigned char* d, long long n, JpegScan& out, boo
   }
   const int mx = (out.w + 8 * out.hmax - 1) / (8 * out.hmax), my = (out.h + 8 * out.vmax - 1) / (8 * out.vmax);
   for (int c = 0; c < out.ncomp; ++c) { out.comp[c].blocks_x = mx * out.comp[c].hs; out.comp[c].blocks_y = my * out.comp[c].vs; }
+  if (head) { head->dri = dri; head->data_off = i; }
   if (header_only) return;
   for (int c = 0; c < out.ncomp; ++c) {
     FFP_CHECK(out.coef[c] != nullptr, FFP_ERR_STATE, "jpeg: no coefficient plane for component %d", c);

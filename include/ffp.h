@@ -278,6 +278,11 @@ int ffp_jpeg_encode_batch_dev(int device, const uint8_t* d_base, int n, const in
 int ffp_jpeg_info(const uint8_t* data, int64_t n, int32_t* out_h, int32_t* out_w, int32_t* out_ncomp);
 int ffp_jpeg_decode(int device, const uint8_t* data, int64_t n, int bgr, uint8_t* out, int64_t cap);
 int ffp_jpeg_decode_dev(int device, const uint8_t* data, int64_t n, int bgr, uint8_t* d_out, int64_t row_stride, int64_t cap);
+/* Since round 3 the Huffman decoding of ffp_jpeg_decode* runs on the device as well (csrc/jpeg_huff.hip: self-synchronising parallel
+ * decoding; the file crosses PCIe as it is). Streams the device decoder flags — damaged data, anything libjpeg treats specially — are
+ * decoded again by the host decoder (FFP_JPEG_HOST_HUFFMAN=1 forces it for every file). Counters since the library was loaded:
+ * files decoded on the device, files that fell back to the host decoder, extra synchronisation rounds (beyond the one queued blindly). */
+int ffp_jpeg_decode_stats(int64_t* device_decodes, int64_t* host_fallbacks, int64_t* extra_sync_rounds);
 
 /* 1x1 conv over the virtual concat [nearest_x2(coarse) | fine] (the YOLO neck's Upsample + Concat + C3k2.cv1 without
  * materialising the upsampled tensor: /root/reference's model graph via ultralytics' yolo11-pose.yaml layers 11-13 and 14-16).

@@ -23,7 +23,8 @@ d = torch.zeros((2160, 3840, 3), dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
 print(f"4K frame, quality 95, 4:2:0: {len(data) / 1e6:.2f} MB file")
 print(f"  decode  libjpeg-turbo (Pillow, 1 core) -> host array          {t(lambda: np.asarray(Image.open(io.BytesIO(data)).convert('RGB')), 5):7.1f} ms")
-print(f"  decode  device codec -> frame in device memory                {t(lambda: _lib.jpeg_decode_dev(data, d.data_ptr(), 3840 * 3, d.numel(), bgr=True), 5):7.1f} ms  (host Huffman decoding into pinned coefficient planes, 37 MB of int16 coefficients over PCIe, IDCT / upsampling / colour on the device)")
+print(f"  decode  device codec -> frame in device memory                {t(lambda: _lib.jpeg_decode_dev(data, d.data_ptr(), 3840 * 3, d.numel(), bgr=True), 5):7.1f} ms  (" + ("host Huffman decoding into pinned coefficient planes, 37 MB of int16 coefficients over PCIe" if os.environ.get("FFP_JPEG_HOST_HUFFMAN") == "1" else "the file over PCIe, Huffman decoding on the device") + ", IDCT / upsampling / colour on the device)")
+print("  decode stats (device, host fallbacks, extra sync rounds):", _lib.jpeg_decode_stats())
 dfr = torch.from_numpy(frame).cuda(); torch.cuda.synchronize()
 print(f"  encode  libjpeg-turbo (Pillow, 1 core) from host array        {t(lambda: Image.fromarray(frame).save(io.BytesIO(), 'JPEG', quality=95), 5):7.1f} ms")
 print(f"  encode  device codec from device memory -> file bytes on host {t(lambda: _lib.jpeg_encode_dev(dfr.data_ptr(), 2160, 3840, 3840 * 3, 95, bgr=False), 5):7.1f} ms")
