@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--cpu-sample", action="store_true", help="CPU baseline on a bounded sample (3 slices + 3 crops) instead of one whole frame")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--secondary-steps", type=int, default=20)
+    ap.add_argument("--secondary-only", default="", help="comma-separated names: measure only these secondary rows (experiments)")
     ap.add_argument("--sr-exclusive", action="store_true", help="experiment: wait for every SR batch before the next detection group (no overlap of the two streams)")
     return ap.parse_args()
 
@@ -533,7 +534,12 @@ def main():
     if not args.no_secondary:
         ss, sw = max(2, args.secondary_steps), max(2, min(args.warmup, 4))
 
+        only = set(x for x in args.secondary_only.split(",") if x)
+
         def sec(name, **kw):
+            if only and name not in only:
+                secondary[name] = {"value": None, "skipped": "--secondary-only"}
+                return None
             # a secondary row must never cost the headline line: a failure (e.g. out of memory in the 4x-larger imgsz-1024 plan) is
             # reported in place of the row; the rows that follow still run
             r = None
@@ -545,7 +551,7 @@ def main():
                 rep = r.report(steps_r)
                 secondary[name] = {"value": round(r.B * steps_r / d, 3), "unit": "frames/s", "ms_per_step": round(d / steps_r * 1e3, 3), "steps": steps_r, "workload": r.describe(),
                                    "frames_per_step": r.B, "det_batch_frames": r.DB, "sr_batch_frames": r.SB, "mode": r.mode, "gathered": bool(r.state.get("gathered", False)),
-                                   "latency_ms_rank0": rep[0]["latency_ms"]}
+                                   "latency_ms_rank0": rep[0]["latency_ms"], "host_stage_ms_per_step_rank0": rep[0]["stage_ms_per_step"]}
                 if world > 1:
                     secondary[name]["per_rank"] = rep
                 if prof_sr and pipe.sr is not None:         # the dominant kernel at THIS row's launch sizes

@@ -544,6 +544,17 @@ int ffp_eval_dual_match(int device, const double* preds, const int64_t* pred_off
 }
 
 // ---- JPEG at the file boundaries -----------------------------------------------------------------------------
+// The file boundaries run beside the detector and the enhancer, whose persistent workgroups hold every CU for the length of a layer:
+// a low-occupancy chain of small kernels (the JPEG codec) on an ordinary stream gets a turn only at kernel boundaries and stretches to
+// tens of milliseconds. Its streams therefore have the highest priority the device offers.
+static hipStream_t io_stream() {
+  int least = 0, greatest = 0;
+  FFP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  hipStream_t st;
+  FFP_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
+  return st;
+}
+
 int ffp_jpeg_encode_dev(int device, const uint8_t* d_img, int h, int w, int64_t row_stride, int bgr, int quality, uint8_t* out, int64_t cap, int64_t* out_size) {
   FFP_API_BEGIN
   FFP_CHECK(out_size, FFP_ERR_ARG, "jpeg_encode: out_size is null");
@@ -551,7 +562,7 @@ int ffp_jpeg_encode_dev(int device, const uint8_t* d_img, int h, int w, int64_t 
   FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "jpeg_encode: no HIP device %d (no CPU path)", device);
   FFP_HIP(hipSetDevice(device));
   hipStream_t st;
-  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  st = io_stream();
   long long n = 0;
   try {
     n = jpeg_encode_device(d_img, h, w, row_stride, bgr, quality, out, cap, st);
@@ -576,7 +587,7 @@ int ffp_jpeg_encode_batch_dev(int device, const uint8_t* d_base, int n, const in
   for (int i = 0; i < n; ++i) src[i] = JpegSrc{d_base + offsets[i], hs[i], ws[i], strides ? strides[i] : (long long)ws[i] * 3};
   std::vector<std::vector<unsigned char>> files;
   hipStream_t st;
-  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  st = io_stream();
   try {
     jpeg_encode_batch_device(src.data(), n, bgr, quality, files, st);
   } catch (...) {
@@ -601,7 +612,7 @@ int ffp_jpeg_encode(int device, const uint8_t* img, int h, int w, int bgr, int q
   DevBuf d((size_t)h * w * 3);
   FFP_HIP(hipMemcpy(d.p, img, (size_t)h * w * 3, hipMemcpyHostToDevice));
   hipStream_t st;
-  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  st = io_stream();
   long long n = 0;
   try {
     n = jpeg_encode_device(d.as<unsigned char>(), h, w, (long long)w * 3, bgr, quality, out, cap, st);
@@ -632,7 +643,7 @@ int ffp_jpeg_decode_dev(int device, const uint8_t* data, int64_t n, int bgr, uin
   FFP_CHECK(hipGetDeviceCount(&ndev) == hipSuccess && device >= 0 && device < ndev, FFP_ERR_HIP, "jpeg_decode: no HIP device %d (no CPU path)", device);
   FFP_HIP(hipSetDevice(device));
   hipStream_t st;
-  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  st = io_stream();
   try {
     jpeg_decode_to_device(data, n, d_out, row_stride, cap, bgr, st, nullptr, nullptr);
   } catch (...) {
@@ -655,7 +666,7 @@ int ffp_jpeg_decode(int device, const uint8_t* data, int64_t n, int bgr, uint8_t
   FFP_CHECK(cap >= (int64_t)bytes, FFP_ERR_ARG, "jpeg_decode: output buffer too small for %dx%d", s.w, s.h);
   DevBuf d(bytes);
   hipStream_t st;
-  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  st = io_stream();
   try {
     jpeg_decode_to_device(data, n, d.as<unsigned char>(), 0, (long long)bytes, bgr, st, nullptr, nullptr);
   } catch (...) {

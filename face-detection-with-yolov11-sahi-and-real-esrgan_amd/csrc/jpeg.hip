@@ -584,12 +584,23 @@ __device__ __forceinline__ void idct8(int (&v)[8], bool first) {
   v[3] = descale(t13 + t0, n); v[4] = descale(t13 - t0, n);
 }
 
-// 8 blocks per workgroup: lane = (block, column) in the first pass, (block, row) in the second; plane row pitch = blocks_x * 8
-__global__ void __launch_bounds__(64) jpeg_idct_kernel(const short* __restrict__ coef, int n_blocks, int blocks_x, const unsigned short* __restrict__ qt,
-                                                       unsigned char* __restrict__ plane) {
+// 8 blocks per workgroup: lane = (block, column) in the first pass, (block, row) in the second; plane row pitch = blocks_x * 8.
+// One launch covers the components of the scan: workgroups [wg0[c], wg0[c + 1]) work on component c.
+struct IdctComp { const short* coef; unsigned char* plane; const unsigned short* qt; int n_blocks, blocks_x, wg0; };
+struct IdctArgs { IdctComp c[3]; int ncomp; };
+__global__ void __launch_bounds__(64) jpeg_idct_kernel(const IdctArgs A) {
   __shared__ int ws[8][64];
+  int ci = 0;
+  if (A.ncomp > 1 && (int)blockIdx.x >= A.c[1].wg0) ci = 1;
+  if (A.ncomp > 2 && (int)blockIdx.x >= A.c[2].wg0) ci = 2;
+  const short* __restrict__ coef = ci == 0 ? A.c[0].coef : ci == 1 ? A.c[1].coef : A.c[2].coef;
+  unsigned char* __restrict__ plane = ci == 0 ? A.c[0].plane : ci == 1 ? A.c[1].plane : A.c[2].plane;
+  const unsigned short* __restrict__ qt = ci == 0 ? A.c[0].qt : ci == 1 ? A.c[1].qt : A.c[2].qt;
+  const int n_blocks = ci == 0 ? A.c[0].n_blocks : ci == 1 ? A.c[1].n_blocks : A.c[2].n_blocks;
+  const int blocks_x = ci == 0 ? A.c[0].blocks_x : ci == 1 ? A.c[1].blocks_x : A.c[2].blocks_x;
+  const int wg0 = ci == 0 ? A.c[0].wg0 : ci == 1 ? A.c[1].wg0 : A.c[2].wg0;
   const int lb = threadIdx.x >> 3, idx = threadIdx.x & 7;
-  const int b = blockIdx.x * 8 + lb;
+  const int b = ((int)blockIdx.x - wg0) * 8 + lb;
   int v[8];
   if (b < n_blocks) {
 #pragma unroll
@@ -658,14 +669,18 @@ __global__ void jpeg_colour_kernel(const unsigned char* __restrict__ py, const u
 
 void JpegDecodeWs::ensure(const JpegScan& s) {
   if (!qt.p) qt = DevBuf(sizeof(unsigned short) * 64 * 4);
+  size_t off[4] = {0, 0, 0, 0};
   for (int c = 0; c < s.ncomp; ++c) {
     const size_t nb = (size_t)s.comp[c].blocks_x * s.comp[c].blocks_y;
     if (nb > cap[c]) {
       cap[c] = nb * 5 / 4 + 64;
-      dev[c] = DevBuf(cap[c] * 64 * sizeof(short));
       plane[c] = DevBuf(cap[c] * 64 + 16);
     }
+    off[c + 1] = off[c] + ((nb * 64 * sizeof(short) + 255) & ~(size_t)255);
   }
+  coef_bytes = off[s.ncomp];
+  if (coef_bytes > coef_all.n) coef_all.alloc(coef_bytes * 5 / 4);
+  for (int c = 0; c < s.ncomp; ++c) dev[c] = reinterpret_cast<short*>(static_cast<unsigned char*>(coef_all.p) + off[c]);
 }
 
 void JpegDecodeWs::ensure_host(const JpegScan& s) {
@@ -711,13 +726,18 @@ void jpeg_ws_release(JpegDecodeWs* ws) {
 
 void jpeg_reconstruct_device(const JpegScan& s, JpegDecodeWs& ws, unsigned char* d_out, long long stride, int bgr, hipStream_t st, bool upload) {
   FFP_HIP(hipMemcpyAsync(ws.qt.p, s.qt, sizeof(unsigned short) * 64 * 4, hipMemcpyHostToDevice, st));
+  IdctArgs A;
+  A.ncomp = s.ncomp;
+  int wg = 0;
+  for (int c = 0; c < 3; ++c) A.c[c] = IdctComp{nullptr, nullptr, nullptr, 0, 1, 0};
   for (int c = 0; c < s.ncomp; ++c) {
     const JpegComp& cp = s.comp[c];
     const int nb = cp.blocks_x * cp.blocks_y;
-    if (upload) FFP_HIP(hipMemcpyAsync(ws.dev[c].p, s.coef[c], (size_t)nb * 64 * sizeof(short), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nb + 7) / 8), dim3(64), 0, st, ws.dev[c].as<short>(), nb, cp.blocks_x, ws.qt.as<unsigned short>() + 64 * cp.tq,
-                       ws.plane[c].as<unsigned char>());
+    if (upload) FFP_HIP(hipMemcpyAsync(ws.dev[c], s.coef[c], (size_t)nb * 64 * sizeof(short), hipMemcpyHostToDevice, st));
+    A.c[c] = IdctComp{ws.dev[c], ws.plane[c].as<unsigned char>(), ws.qt.as<unsigned short>() + 64 * cp.tq, nb, cp.blocks_x, wg};
+    wg += (nb + 7) / 8;
   }
+  hipLaunchKernelGGL(jpeg_idct_kernel, dim3(wg), dim3(64), 0, st, A);
   const int hsub = s.ncomp == 3 ? s.hmax : 1, vsub = s.ncomp == 3 ? s.vmax : 1;
   const int ch = (s.h + vsub - 1) / vsub, cw = (s.w + hsub - 1) / hsub;
   hipLaunchKernelGGL(jpeg_colour_kernel, dim3((s.w + 255) / 256, s.h), dim3(256), 0, st, ws.plane[0].as<unsigned char>(),

@@ -32,8 +32,9 @@ struct JpegHuffWs;                              // buffers of the device entropy
 void jpeg_huff_ws_delete(JpegHuffWs* w);
 struct JpegDecodeWs {
   HostPinned host[3];                           // host-decoder path only (allocated on first use)
-  DevBuf dev[3], plane[3], qt;
-  size_t cap[3] = {0, 0, 0};
+  DevBuf coef_all, plane[3], qt;                // the three coefficient planes are one allocation (one memset clears them)
+  short* dev[3] = {nullptr, nullptr, nullptr};  // component c's plane inside coef_all
+  size_t cap[3] = {0, 0, 0}, coef_bytes = 0;    // coef_bytes: what the current scan uses of coef_all
   int device = 0;                               // the pool hands a workspace out only on the device it was made on
   JpegHuffWs* huff = nullptr;
   JpegDecodeWs() = default;

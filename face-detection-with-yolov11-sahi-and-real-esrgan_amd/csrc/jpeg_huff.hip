@@ -90,13 +90,6 @@ struct Bufs {
 __device__ __forceinline__ bool is_rst(unsigned b) { return b >= 0xD0u && b <= 0xD7u; }
 
 // ---- 1. unstuffing ---------------------------------------------------------------------------------------------------------------------
-__global__ void jh_init_kernel(Bufs b, HuffParams P) {
-  if (threadIdx.x == 0) {
-    b.scal->end = P.n_raw; b.scal->total_clean = 0; b.scal->n_seg = 1; b.scal->T = 0; b.scal->changed = 0; b.scal->err = 0;
-    b.seg_start[0] = 0;
-  }
-}
-
 __global__ void __launch_bounds__(256) jh_end_kernel(Bufs b, HuffParams P) {
   const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   for (int i = i0; i < min(i0 + 4, P.n_raw); ++i) {
@@ -200,37 +193,43 @@ __global__ void __launch_bounds__(256) jh_scatter_kernel(Bufs b, HuffParams P) {
 
 // ---- subsequence layout ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) jh_segs_kernel(Bufs b, HuffParams P, unsigned long long* tmp) {
-  const int n_seg = b.scal->n_seg;
+  const int n_seg = b.scal->n_seg, total_clean = b.scal->total_clean;
   for (int k = threadIdx.x; k < n_seg; k += 1024) {
     const long long bits = (long long)(b.seg_start[k + 1] - b.seg_start[k]) * 8;
     tmp[k] = (unsigned long long)((bits + SUB_BITS - 1) / SUB_BITS);
     if (bits <= 0) atomicOr(&b.scal->err, E_SEGS);          // every MCU needs bits: an empty segment is a damaged file
   }
+  // the decoders look ahead of the bits they consume, and a workgroup stages a fixed window: zeros behind the stream
+  for (int i = threadIdx.x; i < LDS_WORDS * 4 + 64; i += 1024) b.clean[total_clean + i] = 0;
   __syncthreads();
-  const unsigned long long T = block_scan_u64(tmp, n_seg);
+  const unsigned long long Tl = block_scan_u64(tmp, n_seg);
   for (int k = threadIdx.x; k < n_seg; k += 1024) b.first_sub[k] = (int)tmp[k];
+  const int T = (int)min(Tl, (unsigned long long)P.t_cap);
   if (threadIdx.x == 0) {
-    b.first_sub[n_seg] = (int)T;
-    if (T > (unsigned long long)P.t_cap) atomicOr(&b.scal->err, E_CAP);
-    b.scal->T = (int)min(T, (unsigned long long)P.t_cap);
+    b.first_sub[n_seg] = (int)Tl;
+    if (Tl > (unsigned long long)P.t_cap) atomicOr(&b.scal->err, E_CAP);
+    b.scal->T = T;
   }
-}
-
-__global__ void __launch_bounds__(256) jh_subinfo_kernel(Bufs b) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= b.scal->T) return;
-  int lo = 0, hi = b.scal->n_seg;                // the last segment k with first_sub[k] <= t (empty segments share their successor's value)
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (b.first_sub[mid] <= t) lo = mid; else hi = mid;
+  __syncthreads();
+  // every subsequence's segment and first bit
+  for (int t = threadIdx.x; t < T; t += 1024) {
+    int lo = 0, hi = n_seg;                      // the last segment k with first_sub[k] <= t (empty segments share their successor's value)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)tmp[mid] <= t) lo = mid; else hi = mid;
+    }
+    b.sub_seg[t] = lo;
+    b.sub_start[t] = (unsigned)b.seg_start[lo] * 8u + (unsigned)(t - (int)tmp[lo]) * SUB_BITS;
   }
-  b.sub_seg[t] = lo;
-  b.sub_start[t] = (unsigned)b.seg_start[lo] * 8u + (unsigned)(t - b.first_sub[lo]) * SUB_BITS;
 }
 
 // ---- tables --------------------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) jh_tables_kernel(const HuffSpecDev* spec, HuffTabDev* tabs) {
+__global__ void __launch_bounds__(256) jh_tables_kernel(const HuffSpecDev* spec, HuffTabDev* tabs, Bufs b, HuffParams P) {
   __shared__ int s_min[17], s_ptr[17], s_max[17];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {     // the scalars of this decode
+    b.scal->end = P.n_raw; b.scal->total_clean = 0; b.scal->n_seg = 1; b.scal->T = 0; b.scal->changed = 0; b.scal->err = 0;
+    b.seg_start[0] = 0;
+  }
   const HuffSpecDev& sp = spec[blockIdx.x];
   HuffTabDev& t = tabs[blockIdx.x];
   if (threadIdx.x == 0) {
@@ -488,8 +487,8 @@ void jpeg_huff_stats(long long* device_decodes, long long* host_fallbacks, long 
 void jpeg_huff_note_fallback() { g_stat_fallback.fetch_add(1); }
 
 struct JpegHuffWs {
-  HostPinned stage;                              // raw bytes + table specs on their way up, the scalars on their way back
-  DevBuf raw, clean, tiles, tmp, seg_start, first_sub, sub_start, sub_seg, entry, exit_, cnt, pref, tabs, specs, scal;
+  HostPinned stage;                              // table specs + raw bytes on their way up, the scalars on their way back
+  DevBuf raw, clean, tiles, tmp, seg_start, first_sub, sub_start, sub_seg, entry, exit_, cnt, pref, tabs, scal;
   Bufs b;                                        // the decode in flight
   HuffParams P;
   int sub_wgs = 0;
@@ -506,7 +505,8 @@ void queue_scan_and_write(JpegHuffWs& H, const JpegScan& s, JpegDecodeWs& ws, hi
   (void)s; (void)ws;
 }
 void zero_planes(const JpegScan& s, JpegDecodeWs& ws, hipStream_t st) {
-  for (int c = 0; c < s.ncomp; ++c) FFP_HIP(hipMemsetAsync(ws.dev[c].p, 0, (size_t)s.comp[c].blocks_x * s.comp[c].blocks_y * 64 * sizeof(short), st));
+  (void)s;
+  FFP_HIP(hipMemsetAsync(ws.coef_all.p, 0, ws.coef_bytes, st));        // the three planes are one allocation
 }
 }  // namespace
 
@@ -528,7 +528,7 @@ void jpeg_huff_decode_async(const unsigned char* data, long long n, const JpegSc
         FFP_CHECK(P.bpm < 6, FFP_ERR_ARG, "jpeg: more than 6 blocks per MCU");
         P.blk_comp[P.bpm] = c; P.blk_dx[P.bpm] = dx; P.blk_dy[P.bpm] = dy; ++P.bpm;
       }
-    P.coef[c] = ws.dev[c].as<short>();
+    P.coef[c] = ws.dev[c];
   }
   P.mcus_x = s.comp[0].blocks_x / s.comp[0].hs;
   P.total_mcus = P.mcus_x * (s.comp[0].blocks_y / s.comp[0].vs);
@@ -541,45 +541,42 @@ void jpeg_huff_decode_async(const unsigned char* data, long long n, const JpegSc
   const size_t clean_bytes = (size_t)n_raw + LDS_WORDS * 4 + 64;
 
   auto grow = [](DevBuf& d, size_t bytes) { if (bytes > d.n) d.alloc(bytes + (bytes >> 2)); };
-  grow(H.raw, (size_t)n_raw + 16); grow(H.clean, clean_bytes);
+  constexpr size_t SPEC_BYTES = (sizeof(HuffSpecDev) * 6 + 255) & ~(size_t)255;       // [table specs][entropy-coded bytes]: one upload
+  grow(H.raw, SPEC_BYTES + (size_t)n_raw + 16); grow(H.clean, clean_bytes);
   grow(H.tiles, sizeof(unsigned long long) * (size_t)(n_tiles + 1));
   grow(H.tmp, sizeof(unsigned long long) * (size_t)(P.seg_cap + 1));
   grow(H.seg_start, sizeof(int) * (size_t)(P.seg_cap + 2)); grow(H.first_sub, sizeof(int) * (size_t)(P.seg_cap + 2));
   grow(H.sub_start, sizeof(unsigned) * (size_t)P.t_cap); grow(H.sub_seg, sizeof(int) * (size_t)P.t_cap);
   grow(H.entry, sizeof(unsigned long long) * (size_t)P.t_cap); grow(H.exit_, sizeof(unsigned long long) * (size_t)P.t_cap);
   grow(H.cnt, sizeof(int4) * (size_t)P.t_cap); grow(H.pref, sizeof(int4) * (size_t)P.t_cap);
-  grow(H.tabs, sizeof(HuffTabDev) * 6); grow(H.specs, sizeof(HuffSpecDev) * 6); grow(H.scal, sizeof(Scal));
-  const size_t spec_off = ((size_t)n_raw + 63) & ~(size_t)63, scal_off = spec_off + sizeof(HuffSpecDev) * 6;
+  grow(H.tabs, sizeof(HuffTabDev) * 6); grow(H.scal, sizeof(Scal));
+  const size_t scal_off = (SPEC_BYTES + (size_t)n_raw + 63) & ~(size_t)63;
   if (scal_off + sizeof(Scal) > H.stage.n) H.stage.ensure((scal_off + sizeof(Scal)) * 5 / 4);
   unsigned char* hp = static_cast<unsigned char*>(H.stage.p);
-  std::memcpy(hp, data + head.data_off, (size_t)n_raw);
-  HuffSpecDev* specs = reinterpret_cast<HuffSpecDev*>(hp + spec_off);
-  std::memset(specs, 0, sizeof(HuffSpecDev) * 6);
+  HuffSpecDev* specs = reinterpret_cast<HuffSpecDev*>(hp);
+  std::memset(specs, 0, SPEC_BYTES);
   for (int c = 0; c < s.ncomp; ++c)
     for (int k = 0; k < 2; ++k) {
       const JpegHuffSpec& hs = k ? head.ac[s.comp[c].ta] : head.dc[s.comp[c].td];
       std::memcpy(specs[c * 2 + k].bits, hs.bits, 16);
       std::memcpy(specs[c * 2 + k].vals, hs.vals, (size_t)hs.n);
     }
-  FFP_HIP(hipMemcpyAsync(H.raw.p, hp, (size_t)n_raw, hipMemcpyHostToDevice, st));
-  FFP_HIP(hipMemcpyAsync(H.specs.p, specs, sizeof(HuffSpecDev) * 6, hipMemcpyHostToDevice, st));
-  FFP_HIP(hipMemsetAsync(H.clean.p, 0, clean_bytes, st));
+  std::memcpy(hp + SPEC_BYTES, data + head.data_off, (size_t)n_raw);
+  FFP_HIP(hipMemcpyAsync(H.raw.p, hp, SPEC_BYTES + (size_t)n_raw, hipMemcpyHostToDevice, st));
   zero_planes(s, ws, st);
 
   Bufs b;
-  b.raw = H.raw.as<unsigned char>(); b.clean = H.clean.as<unsigned char>(); b.tile_cnt = H.tiles.as<unsigned long long>();
+  b.raw = H.raw.as<unsigned char>() + SPEC_BYTES; b.clean = H.clean.as<unsigned char>(); b.tile_cnt = H.tiles.as<unsigned long long>();
   b.seg_start = H.seg_start.as<int>(); b.first_sub = H.first_sub.as<int>(); b.sub_start = H.sub_start.as<unsigned>(); b.sub_seg = H.sub_seg.as<int>();
   b.entry = H.entry.as<unsigned long long>(); b.exit_ = H.exit_.as<unsigned long long>(); b.cnt = H.cnt.as<int4>(); b.pref = H.pref.as<int4>();
   b.tabs = H.tabs.as<HuffTabDev>(); b.scal = H.scal.as<Scal>();
   H.b = b; H.P = P; H.sub_wgs = (P.t_cap + NT - 1) / NT; H.scal_off = scal_off;
-  hipLaunchKernelGGL(jh_init_kernel, dim3(1), dim3(64), 0, st, b, P);
-  hipLaunchKernelGGL(jh_tables_kernel, dim3(6), dim3(256), 0, st, H.specs.as<HuffSpecDev>(), H.tabs.as<HuffTabDev>());
+  hipLaunchKernelGGL(jh_tables_kernel, dim3(6), dim3(256), 0, st, H.raw.as<HuffSpecDev>(), H.tabs.as<HuffTabDev>(), b, P);
   hipLaunchKernelGGL(jh_end_kernel, dim3(n_tiles), dim3(256), 0, st, b, P);
   hipLaunchKernelGGL(jh_count_kernel, dim3(n_tiles), dim3(256), 0, st, b, P);
   hipLaunchKernelGGL(jh_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, b, P, n_tiles, n_seg_expected);
   hipLaunchKernelGGL(jh_scatter_kernel, dim3(n_tiles), dim3(256), 0, st, b, P);
   hipLaunchKernelGGL(jh_segs_kernel, dim3(1), dim3(1024), 0, st, b, P, H.tmp.as<unsigned long long>());
-  hipLaunchKernelGGL(jh_subinfo_kernel, dim3((P.t_cap + 255) / 256), dim3(256), 0, st, b);
   hipLaunchKernelGGL(jh_sync_kernel<true>, dim3(H.sub_wgs), dim3(NT), 0, st, b, P);
   hipLaunchKernelGGL(jh_sync_kernel<false>, dim3(H.sub_wgs), dim3(NT), 0, st, b, P);
   queue_scan_and_write(H, s, ws, st);
