@@ -270,11 +270,11 @@ int ffp_jpeg_encode_batch_dev(int device, const uint8_t* d_base, int n, const in
 /* Replaces `cv2.imread(path)` for .jpg files (/root/reference/utils/enhancer.py:254, utils/visualization.py:200, and the image
  * load inside sahi's get_sliced_prediction): baseline / extended-sequential 8-bit JFIF, 4:4:4 / 4:2:2 / 4:2:0 or grayscale, restart
  * intervals; libjpeg's default reconstruction (integer IDCT, triangle chroma upsampling, fixed-point YCbCr -> RGB), pixel-identical
- * to what libjpeg-turbo returns. The Huffman decoder runs on the host (a serial bit stream); IDCT, upsampling and colour conversion
- * run on the device. Progressive / arithmetic-coded files: FFP_ERR_ARG. ffp_jpeg_info reads the header only. out: h*w*3 bytes, BGR
+ * to what libjpeg-turbo returns. Huffman decoding (see ffp_jpeg_decode_stats below), IDCT, upsampling and colour conversion all run
+ * on the device; the host parses the markers. Progressive / arithmetic-coded files: FFP_ERR_ARG. ffp_jpeg_info reads the header only. out: h*w*3 bytes, BGR
  * when bgr = 1 (cv2's order; grayscale files give three equal channels like IMREAD_COLOR). _dev writes into device memory (row
- * pitch in bytes): the frame is ready for ffp_det_infer_tiles_dev; what crosses PCIe are the quantised coefficients (int16, from pinned
- * staging planes kept in a pool), the pixels are never materialised on the host. */
+ * pitch in bytes): the frame is ready for ffp_det_infer_tiles_dev; what crosses PCIe is the file itself (through pinned staging kept in a
+ * pool), neither coefficients nor pixels are ever materialised on the host. */
 int ffp_jpeg_info(const uint8_t* data, int64_t n, int32_t* out_h, int32_t* out_w, int32_t* out_ncomp);
 int ffp_jpeg_decode(int device, const uint8_t* data, int64_t n, int bgr, uint8_t* out, int64_t cap);
 int ffp_jpeg_decode_dev(int device, const uint8_t* data, int64_t n, int bgr, uint8_t* d_out, int64_t row_stride, int64_t cap);
