@@ -2,8 +2,9 @@
 WIDER FACE protocol (easy / medium / hard AP from the .mat ground truth). The per-image matching and the per-threshold PR counts —
 `_image_eval` :302-347 + `_img_pr_info` :349-375, the O(images x predictions x faces) part, including the `bbox_overlaps` the reference
 imports from a Cython extension (:24-33) — run in ONE launch on the GPU (ffp_eval_wider_pr); `_dataset_pr_info` and `_voc_ap` are the
-reference's few numpy lines on the resulting integer counts. Inference (`_run_single_inference` :185-255) goes through this build's
-`utils.yolo_wrapper` / `sahi.predict` shims; predictions can also be handed in (`run(all_predictions=...)`), which is how the tests
+reference's few numpy lines on the resulting integer counts. Inference (`_run_single_inference` :166-255, all four pipelines: baseline,
+SAHI, enhance -> detect, enhance -> SAHI, with full or bounded enhancement) goes through this build's `utils.yolo_wrapper` /
+`utils.enhancer` / `sahi.predict` shims; predictions can also be handed in (`run(all_predictions=...)`), which is how the tests
 drive it (no WIDER FACE data or trained weights exist on the build machine). Plots (matplotlib) are left to the caller.
 """
 from collections import defaultdict
@@ -26,17 +27,44 @@ class OfficialWiderFaceEvaluator:
         self.use_enhancer, self.bounded_enhancement, self.face_size_threshold = use_enhancer, bounded_enhancement, face_size_threshold
         self.inference_confidence = 0.01
         self.sahi_config = {"slice_height": 640, "slice_width": 640, "overlap_ratio": 0.2} if slicing_strategy == "uniform" else {"overlap_ratio": 0.2}
-        if use_enhancer:
-            raise NotImplementedError("enhance-first evaluation modes: run FramePipeline.enhance_first and pass the predictions to run()")
+        self.enhancement_stats = defaultdict(lambda: {"enhanced": 0, "skipped": 0, "total": 0})
         self.detection_model = None
+        self.face_enhancer = None
         if load_model:
             from utils.yolo_wrapper import YOLOv11PoseDetectionModel
             self.detection_model = YOLOv11PoseDetectionModel(model_path=model_path, confidence_threshold=self.inference_confidence, device=device, load_at_init=True)
+            if self.use_enhancer:                                      # :90-98: a failing enhancer switches the mode off, it does not abort
+                try:
+                    from utils.enhancer import FaceEnhancer
+                    self.face_enhancer = FaceEnhancer(model_name="RealESRGAN_x2plus")
+                    print(f"   ✓ Model Enhancer dimuat! (Skala: {self.face_enhancer.scale}x)")
+                except Exception as e:
+                    print(f"   ❌ Gagal memuat model Enhancer: {e}. Enhancement dinonaktifkan.")
+                    self.use_enhancer = False
         self._build_mode_string()
         self._load_official_ground_truth()
 
     def _build_mode_string(self):
-        self.mode_string = f"SAHI ({self.slicing_strategy})" if self.use_sahi else "BASELINE"
+        """:103-116 (the official evaluator joins with ' -> ')"""
+        mode_parts = []
+        if self.use_enhancer:
+            mode_parts.append(f"BOUNDED-ENHANCE (<{self.face_size_threshold}px)" if self.bounded_enhancement else "FULL-ENHANCE")
+        mode_parts.append(f"SAHI ({self.slicing_strategy})" if self.use_sahi else "BASELINE")
+        self.mode_string = " -> ".join(mode_parts)
+
+    def _quick_face_analysis(self, img):
+        """Bounded enhancement's decision (:147-158): a plain predict at conf 0.05; enhance when nothing is found, when more than half of
+        the faces are smaller than face_size_threshold (longer side) or when their mean size is."""
+        if img is None:
+            return False, "Image load failed", {}
+        results = self.detection_model.model(img, conf=0.05, verbose=False)
+        if len(results) == 0 or results[0].boxes is None or len(results[0].boxes) == 0:
+            return True, "No faces detected", {}
+        face_sizes = [max(box[2] - box[0], box[3] - box[1]) for box in results[0].boxes.xyxy.cpu().numpy()]
+        small_face_ratio = sum(1 for sz in face_sizes if sz < self.face_size_threshold) / len(face_sizes)
+        if small_face_ratio > 0.5 or np.mean(face_sizes) < self.face_size_threshold:
+            return True, f"Small faces detected (ratio: {small_face_ratio:.2f})", {}
+        return False, "Faces are large enough", {}
 
     def _load_official_ground_truth(self):
         from scipy.io import loadmat
@@ -58,6 +86,23 @@ class OfficialWiderFaceEvaluator:
         img = cv2.imread(str(img_path))
         if img is None:
             return np.array([])
+        # 1. enhancement phase (:174-186): the whole picture through Real-ESRGAN x2plus, always or when the quick analysis says so
+        inference_img, was_enhanced = img, False
+        if getattr(self, "use_enhancer", False) and getattr(self, "face_enhancer", None):
+            enhance_decision = self._quick_face_analysis(img)[0] if self.bounded_enhancement else True
+            if enhance_decision:
+                enhanced_image, success = self.face_enhancer.enhance_image(img)
+                if success:
+                    inference_img, was_enhanced = enhanced_image, True
+        img = inference_img
+        pred = self._detect(img)
+        # 3. boxes of an upscaled picture go back to the original's coordinates (:246-251)
+        if was_enhanced and self.face_enhancer.scale > 1 and len(pred) > 0:
+            pred[:, :4] /= self.face_enhancer.scale
+        return pred.astype("float")
+
+    def _detect(self, img):
+        """2. detection phase (:188-243) on the picture to infer on"""
         if self.use_sahi:
             from sahi.predict import get_sliced_prediction
             cfg = dict(self.sahi_config)

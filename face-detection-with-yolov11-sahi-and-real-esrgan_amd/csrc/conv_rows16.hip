@@ -468,7 +468,8 @@ void launch_conv_rows16(ConvArgs& a, const PackedConv& pc, Level* out_lvl, hipSt
   long long per_xcd = (items + 7) / 8;
   per_xcd = (per_xcd + a.n_nblk - 1) / a.n_nblk * a.n_nblk;
   const bool res = rows16_resident(a);
-  long long ws = std::max<long long>(res ? 32 : 64, (per_xcd + G::TCAP - 1) / G::TCAP);          // resident weights: one workgroup per CU
+  static const int ws_env = [] { const char* e = getenv("FFP_ROWS16_WS"); return e ? atoi(e) : 0; }();      // experiment: workgroups per XCD (64 = two per CU)
+  long long ws = std::max<long long>(ws_env > 0 ? ws_env : (res ? 32 : 64), (per_xcd + G::TCAP - 1) / G::TCAP);          // resident weights: one workgroup per CU
   ws = (ws + a.n_nblk - 1) / a.n_nblk * a.n_nblk;
   FFP_CHECK(8 * ws < (1ll << 31) && (per_xcd + ws - 1) / ws <= G::TCAP, FFP_ERR_STATE, "rows16: launch geometry");
   r16_for_mask<>(a.dbg, res, false, &a, (unsigned)(8 * ws), res ? G::res_lds(a.cin >> 5) : G::LDS, st);

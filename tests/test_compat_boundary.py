@@ -243,3 +243,110 @@ def test_official_evaluator_hands_the_detector_what_the_reference_does(shims, tm
     assert seen["sahi_img"][0, 0].tolist() == [0, 0, 200]
     assert seen["sahi_kw"] == dict(slice_height=640, slice_width=640, overlap_height_ratio=0.2, overlap_width_ratio=0.2, postprocess_type="NMS",
                                    postprocess_match_threshold=0.5, postprocess_class_agnostic=True, verbose=0)
+
+
+def test_evaluator_enhancement_modes_plumbing(shims, tmp_path, monkeypatch):
+    """eval/eval_official_widerface.py:166-255 and eval/eval_dual.py:182-270, the four pipelines: the enhancement phase (always, or when
+    the quick analysis at conf 0.05 finds no / mostly small faces), detection on the enhanced picture, boxes divided by the enhancer's
+    scale; mode strings (' -> ' in the official evaluator, ' + ' in the dual one); statistics and the per-path cache of the dual one."""
+    from PIL import Image
+    import torch
+    from eval.eval_dual import DualWiderFaceEvaluator
+    from eval.eval_official_widerface import OfficialWiderFaceEvaluator
+    p = str(tmp_path / "pic.png")
+    Image.fromarray(np.full((40, 60, 3), 90, np.uint8)).save(p)
+    calls = []
+
+    class _B:
+        def __init__(self, rows):
+            self.xyxy = torch.tensor(rows, dtype=torch.float32).reshape(-1, 5)[:, :4]
+            self.conf = torch.tensor(rows, dtype=torch.float32).reshape(-1, 5)[:, 4]
+        def __len__(self):
+            return self.xyxy.shape[0]
+
+    class _Yolo:
+        faces = [[10.0, 10.0, 30.0, 40.0, 0.9]]                        # what the quick analysis sees
+        def __call__(self, img, **kw):
+            calls.append((img.shape, kw["conf"]))
+            if kw["conf"] == 0.05:
+                rows = self.faces
+            else:                                                      # the real pass: one box that scales with the picture
+                rows = [[img.shape[1] / 4, img.shape[0] / 4, img.shape[1] / 2, img.shape[0] / 2, 0.75]]
+            class _R:
+                boxes = _B(rows)
+            return [_R()]
+
+    class _DM:
+        model = _Yolo()
+
+    class _Enh:
+        scale = 2
+        n = 0
+        def enhance_image(self, img):
+            _Enh.n += 1
+            return np.repeat(np.repeat(img, 2, 0), 2, 1), True
+
+    def official(**kw):
+        ev = OfficialWiderFaceEvaluator.__new__(OfficialWiderFaceEvaluator)
+        ev.use_sahi, ev.slicing_strategy, ev.inference_confidence, ev.face_size_threshold = False, "uniform", 0.01, 50
+        ev.use_enhancer, ev.bounded_enhancement = kw.get("enh", False), kw.get("bounded", False)
+        ev.sahi_config = {"slice_height": 640, "slice_width": 640, "overlap_ratio": 0.2}
+        ev.detection_model, ev.face_enhancer = _DM(), (_Enh() if ev.use_enhancer else None)
+        ev._build_mode_string()
+        return ev
+
+    base = official()._run_single_inference(p)
+    assert np.allclose(base, [[15, 10, 15, 10, 0.75]]) and official().mode_string == "BASELINE"
+    ev = official(enh=True)
+    n0 = _Enh.n
+    out = ev._run_single_inference(p)
+    assert _Enh.n == n0 + 1 and calls[-1] == ((80, 120, 3), 0.01)      # detection ran on the x2 picture ...
+    assert np.allclose(out, base) and ev.mode_string == "FULL-ENHANCE -> BASELINE"          # ... and its boxes came back to the original's coordinates
+    ev = official(enh=True, bounded=True)
+    assert ev.mode_string == "BOUNDED-ENHANCE (<50px) -> BASELINE"
+    _Yolo.faces = [[0.0, 0.0, 60.0, 70.0, 0.9], [0.0, 0.0, 80.0, 55.0, 0.8]]       # large faces: no enhancement
+    n0 = _Enh.n
+    out = ev._run_single_inference(p)
+    assert _Enh.n == n0 and calls[-2:] == [((40, 60, 3), 0.05), ((40, 60, 3), 0.01)] and np.allclose(out, base)
+    _Yolo.faces = [[0.0, 0.0, 20.0, 30.0, 0.9], [0.0, 0.0, 80.0, 55.0, 0.8], [0.0, 0.0, 10.0, 12.0, 0.8]]     # two of three are small
+    out = ev._run_single_inference(p)
+    assert _Enh.n == n0 + 1 and np.allclose(out, base)
+    assert ev._quick_face_analysis(None)[0] is False
+    _Yolo.faces = []
+    assert ev._quick_face_analysis(np.zeros((8, 8, 3), np.uint8))[:2] == (True, "No faces detected")
+    official_sahi = official(enh=True)
+    official_sahi.use_sahi = True
+    official_sahi._build_mode_string()
+    assert official_sahi.mode_string == "FULL-ENHANCE -> SAHI (uniform)"
+
+    # the dual evaluator: same phases, dict rows, statistics, cache, ' + '
+    _Yolo.faces = [[0.0, 0.0, 20.0, 30.0, 0.9]]
+    d = DualWiderFaceEvaluator(subcategory_gt={}, use_enhancer=True, bounded_enhancement=True)
+    assert d.mode_string == "BOUNDED-ENHANCE (<50px) + BASELINE" and d.inference_confidence == 0.5
+    d.detection_model, d.face_enhancer = _DM(), _Enh()
+    rows = d.run_inference(p)
+    assert len(rows) == 1 and np.allclose(rows[0]["bbox"], [15, 10, 15, 10]) and abs(rows[0]["confidence"] - 0.75) < 1e-6
+    assert d.enhancement_stats["enhanced_images"] == 1 and d.run_inference(p) is rows            # cached
+    _Yolo.faces = [[0.0, 0.0, 90.0, 90.0, 0.9]]
+    p2 = str(tmp_path / "pic2.png")
+    Image.fromarray(np.full((40, 60, 3), 30, np.uint8)).save(p2)
+    d.run_inference(p2)
+    assert d.enhancement_stats == {"total_images": 0, "enhanced_images": 1, "skipped_images": 1}
+    assert d.run_inference(str(tmp_path / "missing.jpg")) == []
+    ds = DualWiderFaceEvaluator(subcategory_gt={}, use_sahi=True, use_enhancer=True, slicing_strategy="adaptive", sahi_match_thresholds=[0.4])
+    assert ds.mode_string == "FULL-ENHANCE + SAHI (adaptive)" and ds.inference_confidence == 0.01
+    assert ds.sahi_config["postprocess_match_thresholds"] == [0.4] and ds.sahi_config["overlap_ratio"] == 0.2 and "slice_height" not in ds.sahi_config
+    assert DualWiderFaceEvaluator(subcategory_gt={}).sahi_config["overlap_ratio"] == 0.25
+    assert [ds.get_slice_size_adaptive(w, 10) for w in (2501, 2500, 1501, 1500)] == [512, 416, 416, 320]
+    seen = {}
+    import sahi.predict as sp
+    def fake_gsp(image, model, **kw):
+        seen["shape"], seen["kw"] = image.shape, kw
+        class _Res:
+            object_prediction_list = []
+        return _Res()
+    monkeypatch.setattr(sp, "get_sliced_prediction", fake_gsp)
+    ds.detection_model, ds.face_enhancer = _DM(), _Enh()
+    assert ds.run_inference(p) == []
+    assert seen["shape"] == (80, 120, 3) and seen["kw"]["slice_height"] == 320 and seen["kw"]["postprocess_match_threshold"] == 0.4
+    assert seen["kw"]["postprocess_type"] == "NMS" and seen["kw"]["postprocess_match_metric"] == "IOS" and seen["kw"]["postprocess_class_agnostic"] is True

@@ -205,3 +205,62 @@ def test_enhance_first_at_reference_settings(gpu_lib):
     assert eb.shape[0] > 0 and abs(k - eb.shape[0]) <= max(1, eb.shape[0] // 50), (k, eb.shape[0])
     ious = np.array([x[2] for x in match_by_iou(eb, got)])
     assert (ious >= 0.999).mean() >= 0.95, ious
+
+
+def test_evaluator_full_pipeline_mode_through_the_shims(compat, tmp_path):
+    """The evaluators' fourth pipeline, 'Enhance + SAHI + YOLO' (eval/eval_dual.py:24-31,185-265; eval_official_widerface.py:166-255):
+    JPEG file -> cv2.imread -> FaceEnhancer('RealESRGAN_x2plus').enhance_image (23 blocks, tile 400, fp16) -> get_sliced_prediction on the
+    2x picture (NMS / IOS / 0.5, class-agnostic, 640 slices) -> boxes / 2. Checked against the same steps made by hand through the
+    library, and against the oracle's detector run on the enhanced picture the device produced."""
+    import cv2
+    from eval.eval_dual import DualWiderFaceEvaluator
+    from eval.eval_official_widerface import OfficialWiderFaceEvaluator
+    from sahi.predict import get_sliced_prediction
+    from utils.enhancer import FaceEnhancer
+    from utils.yolo_wrapper import YOLOv11PoseDetectionModel
+    from oracle import sahi_ref, ultra_post
+    from oracle.yolo11_ref import Yolo11PoseRef
+    from ffp_amd import synth
+    p = str(tmp_path / "0_Parade_marchingband_1_5.jpg")
+    _jpeg_frame(p, 360, 480, seed=5)
+    model = YOLOv11PoseDetectionModel(model_path="synthetic:yolo11n-pose", confidence_threshold=0.01, device="cuda:0", load_at_init=True)
+    enhancer = FaceEnhancer(model_name="RealESRGAN_x2plus", model_path="synthetic:RealESRGAN_x2plus")
+    assert enhancer.scale == 2
+
+    d = DualWiderFaceEvaluator(subcategory_gt={}, use_sahi=True, use_enhancer=True)
+    d.detection_model, d.face_enhancer = model, enhancer
+    assert d.mode_string == "FULL-ENHANCE + SAHI (uniform)"
+    rows = d.run_inference(p)
+    assert d.enhancement_stats["enhanced_images"] == 1 and len(rows) > 0
+
+    o = OfficialWiderFaceEvaluator.__new__(OfficialWiderFaceEvaluator)
+    o.use_sahi, o.slicing_strategy, o.inference_confidence, o.face_size_threshold = True, "uniform", 0.01, 50
+    o.use_enhancer, o.bounded_enhancement = True, False
+    o.sahi_config = {"slice_height": 640, "slice_width": 640, "overlap_ratio": 0.2}
+    o.detection_model, o.face_enhancer = model, enhancer
+    o._build_mode_string()
+    assert o.mode_string == "FULL-ENHANCE -> SAHI (uniform)"
+    out = o._run_single_inference(p)
+
+    # by hand, the same library calls
+    img = cv2.imread(p)
+    big, ok = enhancer.enhance_image(img)
+    assert ok and big.shape == (720, 960, 3)
+    for overlap, got in ((0.25, np.asarray([[*r["bbox"], r["confidence"]] for r in rows], np.float64)), (0.2, out)):
+        res = get_sliced_prediction(big, model, slice_height=640, slice_width=640, overlap_height_ratio=overlap, overlap_width_ratio=overlap,
+                                    postprocess_type="NMS", postprocess_match_metric="IOS", postprocess_match_threshold=0.5, postprocess_class_agnostic=True, verbose=0)
+        want = np.asarray([[*q.bbox.to_xywh(), q.score.value] for q in res.object_prediction_list], np.float64).reshape(-1, 5)
+        want[:, :4] /= 2
+        assert got.shape == want.shape and np.array_equal(got, want)
+    # the oracle's detector + SAHI on that enhanced picture. The evaluator hands sahi the BGR array cv2 produced; sahi takes arrays for RGB
+    # (read_image_as_pil), the wrapper flips to BGR, Ultralytics flips back: the network sees the array AS IT IS (R and B swapped w.r.t.
+    # the file — the reference's behaviour, kept)
+    ref = Yolo11PoseRef(synth.yolo11_pose_weights("n"), "n")
+    exp = sahi_ref.get_sliced_prediction(np.ascontiguousarray(big), lambda im: ultra_post.predict(ref, im, 1024, 0.01, 0.7, 300), 640, 640, 0.2, 0.2, True,
+                                         "NMS", "IOS", 0.5, True)                # image_size 1024: the wrapper's default (utils/yolo_wrapper.py:13)
+    eb = np.asarray([q.bbox for q in exp], np.float32).reshape(-1, 4)
+    gb = out[:, :4].copy() * 2
+    gb[:, 2:] += gb[:, :2]
+    assert eb.shape[0] > 0 and abs(gb.shape[0] - eb.shape[0]) <= max(1, eb.shape[0] // 25), (gb.shape, eb.shape)
+    ious = np.array([x[2] for x in match_by_iou(eb, gb.astype(np.float32))])
+    assert (ious >= 0.999).mean() >= 0.95, ious
