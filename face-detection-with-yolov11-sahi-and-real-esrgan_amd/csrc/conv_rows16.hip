@@ -32,6 +32,9 @@
 #ifndef FFP_R16_PRIO
 #define FFP_R16_PRIO 0         // 1: s_setprio 1 over the MFMA stream of a chunk (A/B)
 #endif
+#ifndef FFP_R16_STASH
+#define FFP_R16_STASH 0        // experiment: 1 = the next chunk's ten pieces are written to LDS and re-requested BEFORE the chunk's MFMA stream, 2 = AFTER it
+#endif                         //             (0: one piece per MFMA step, the shipped schedule)
 #ifndef FFP_R16_STAMP
 #define FFP_R16_STAMP 0        // 1: diagnostic build — s_memtime stamps around the phases of every chunk, sums printed by the first workgroups
 #endif                         //    (MI355X guide, "In-kernel stamps"); never in a shipped build, the stamps cost ~10 % of the kernel
@@ -250,6 +253,11 @@ __global__ void __launch_bounds__(256, (RES ? 1 : 2)) conv_rows16_kernel(const C
 #pragma unroll
       for (int m = 0; m < 2; ++m) aq[q][m] = *reinterpret_cast<const uint4*>((RES ? wres : sb) + aoff + ((tap * 2 + m) << 10));
     };
+#if FFP_R16_STASH == 1
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { piece_stash(sbn, p, set[p]); piece_fetch(p, set[p]); }
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     ldB(0, 0);
     ldA(0, 0);
     ldA(1, 1);
@@ -267,11 +275,13 @@ __global__ void __launch_bounds__(256, (RES ? 1 : 2)) conv_rows16_kernel(const C
       if (s + 2 < 9) ldA(s + 2, (s + 2) % 3);
       if (ky == 0 && kx < 2) ldB(kx + 1, (kx + 1) & 1);
       // staging slots per step: {0} {1} {2} {3} {4} {5} {6} {7} {8, 9}
+#if FFP_R16_STASH == 0
 #pragma unroll
       for (int p = s; p < (RES ? (s < NP ? s + 1 : s) : (s == 8 ? 10 : s + 1)); ++p) {
         piece_stash(sbn, p, set[p]);
         piece_fetch(p, set[p]);
       }
+#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -291,6 +301,10 @@ __global__ void __launch_bounds__(256, (RES ? 1 : 2)) conv_rows16_kernel(const C
     }
 #if FFP_R16_PRIO
     __builtin_amdgcn_s_setprio(0);
+#endif
+#if FFP_R16_STASH == 2
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { piece_stash(sbn, p, set[p]); piece_fetch(p, set[p]); }
 #endif
     advance_pf();
   };
