@@ -64,6 +64,11 @@ def parse():
                     help="frames whose crops are enhanced together as one ragged Real-ESRGAN batch (1: per frame)")
     ap.add_argument("--det-batch-frames", type=int, default=5,
                     help="consecutive steps whose frames are detected together as one ragged batch of slices (1: per step)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="pipeline lanes per process: L detector + enhancer handle pairs driven by L host threads, detection groups dealt round-robin "
+                         "(their kernels interleave on the card: +4-6 %% frames/s, see secondary.two_lanes); 1 = one lane, the headline's configuration — "
+                         "with several lanes the event-timed launches of the dominant kernel overlap another lane's kernels and its roofline line stops "
+                         "describing the kernel. Only where the ranks run independent frames (no collective in the loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", action="store_true", help="CPU baseline on a bounded sample (3 slices + 3 crops) instead of one whole frame")
     ap.add_argument("--no-secondary", action="store_true")
@@ -147,8 +152,13 @@ class Runner:
     """One configuration of the hot path: its pipeline, its resident plans, its timed loop."""
 
     def __init__(self, args, ctx, *, det_precision=None, imgsz=None, pp_type=None, class_agnostic=None, sr_sizes=None, frames_per_step=None,
-                 exchange=None, resident=None, pipe=None, det_batch=None, sr_batch=None, jpeg_io=False):
+                 exchange=None, resident=None, pipe=None, pipes=None, det_batch=None, sr_batch=None, jpeg_io=False, lanes=None, _lane=0, _n_lanes=None):
         import torch
+        kw = dict(det_precision=det_precision, imgsz=imgsz, pp_type=pp_type, class_agnostic=class_agnostic, sr_sizes=sr_sizes, frames_per_step=frames_per_step,
+                  exchange=exchange, resident=resident, det_batch=det_batch, sr_batch=sr_batch, jpeg_io=jpeg_io)
+        if pipes is None and pipe is not None:
+            pipes = [pipe]
+        pipe = pipes[_lane] if pipes is not None and _lane < len(pipes) else None
         from ffp_amd import _lib, pipeline, synth
         self.torch, self.pipeline, self.ctx, self.args = torch, pipeline, ctx, args
         self.rank, self.world, self.dev = ctx["rank"], ctx["world"], ctx["dev"]
@@ -171,6 +181,12 @@ class Runner:
         else:
             self.mode = "global"
         self.Bl = self.B if self.mode == "global" else 1          # frames of one step in THIS rank's super-frame
+        # lanes: this object is lane `lane` of `n_lanes`; lane 0 owns the others (self.sub) and runs them on threads. Detection groups are dealt
+        # round-robin, so the lanes together process exactly the single-lane sequence of frames, crops and seeds. Never with a collective in
+        # the loop (two threads of a rank would have to issue collectives in one order on every rank).
+        self.lane = _lane
+        self.n_lanes = _n_lanes if _n_lanes is not None else (max(1, lanes if lanes is not None else args.lanes) if self.mode == "local" else 1)
+        self.sub = []
         self.resident = args.resident if resident is None else resident
         self.H, self.W = args.height, args.width
         self.DB = max(1, det_batch or args.det_batch_frames)
@@ -209,6 +225,10 @@ class Runner:
         self.sr_px = 0
         self.tm = {}                                   # host-side wall time per stage over the timed loop (seconds)
         self.lat_t0, self.lat = {}, []                 # per-frame latency: handed to the pipeline -> enhanced crops on the host
+        if _n_lanes is None and self.n_lanes > 1:
+            self.sub = [Runner(args, ctx, pipes=pipes, _lane=k, _n_lanes=self.n_lanes, **kw) for k in range(1, self.n_lanes)]
+        self.pipes = [self.pipe] + [r.pipe for r in self.sub]
+        self.prof_pipe = self.pipe                     # the lane whose last group / SR batch carries the kernel events (loop())
 
     # ---- frames: pinned host super-frames, three device slots per super-frame size, uploads on a copy stream ----------------
     def frame_of(self, variant, f):
@@ -241,7 +261,8 @@ class Runner:
                 self.slots[key] = self.host_super(nf, variant).to(self.dev)
                 torch.cuda.synchronize(self.dev)
             return self.slots[key], None
-        key = (nf, gi % self.nslots)
+        self.up_seq = getattr(self, "up_seq", -1) + 1          # this lane's own upload count (its groups are every n_lanes-th one): the ring position
+        key = (nf, self.up_seq % self.nslots)
         if any(x[0] == key for x in self.queue):
             raise RuntimeError("frame slot ring too small: a slot with queued crops would be overwritten")
         if key in self.pending.get("slots", ()):
@@ -346,7 +367,7 @@ class Runner:
         sf, ev = self.group.pop("next")
         slot_key = self.group.pop("next_key")
         if nxt is not None:
-            self.group["next"] = self.upload(gi + 1, Bl * nxt[1])         # overlaps this group's detection
+            self.group["next"] = self.upload(nxt[0], Bl * nxt[2])         # this lane's next group: overlaps this group's detection
             self.group["next_key"] = self.state["slot_key"]
         t0 = time.perf_counter()
         if ev is not None:
@@ -365,7 +386,7 @@ class Runner:
         self.state["gathered"] = gathered
         my = 0 if self.mode == "local" else self.rank
         for i in range(g0, g0 + gsz):
-            last = profile and i == n_total - 1
+            last = profile and i == g0 + gsz - 1
             for fb in range(Bl):
                 f = (i - g0) * Bl + fb
                 spread = L.owner(f) < 0                                                   # this frame's items live on several ranks
@@ -398,8 +419,10 @@ class Runner:
                 prof = self.prof_flush is not None and self.flush_no == self.prof_flush     # the kernel times of ONE whole SR batch
                 if prof:
                     self.drain_sr()
+                    for ev_done in getattr(self, "_wait_for", ()):       # the profiled SR batch runs with the card to itself: the other lanes (which own no
+                        ev_done.wait()                                   # later group) finish their last batches first
                     pipe.sr.set_profile(True)
-                self.flush_sr(slot=(i // self.SB) & 1)
+                self.flush_sr(slot=self.flush_no & 1)
                 if a.sr_exclusive:
                     self.drain_sr()                                                      # experiment: the enhancer never runs beside the detector
                 if prof:
@@ -408,21 +431,58 @@ class Runner:
                     pipe.sr.set_profile(False)
                 self.flush_no += 1
 
-    def loop(self, n_steps, profile_last=False):
-        gs = self.groups(n_steps)
-        if not gs:                                     # --warmup 0
+    def my_groups(self, n_steps):
+        """This lane's share of the loop: (global group index, first global step, steps) of every n_lanes-th group."""
+        return [(gi, g0, gsz) for gi, (g0, gsz) in enumerate(self.groups(n_steps)) if gi % self.n_lanes == self.lane]
+
+    def loop_own(self, n_steps, profile_last=False):
+        gs = self.my_groups(n_steps)
+        if not gs:                                     # --warmup 0, or fewer groups than lanes
             return
         # SR kernels are profiled on the last FULL batch of the loop (a trailing partial batch would understate the launch sizes)
-        n_flush = -(-(n_steps * self.Bl) // self.SB) if self.args.sr_crops > 0 else 0
-        n_full = (n_steps * self.Bl) // self.SB
+        own = sum(g[2] for g in gs)
+        n_flush = -(-(own * self.Bl) // self.SB) if self.args.sr_crops > 0 else 0
+        n_full = (own * self.Bl) // self.SB
         self.prof_flush = (max(n_full, 1) - 1 if n_flush else None) if profile_last else None
         self.flush_no = 0
-        self.group["next"] = self.upload(0, self.Bl * gs[0][1])
+        self.group["next"] = self.upload(gs[0][0], self.Bl * gs[0][2])
         self.group["next_key"] = self.state["slot_key"]
-        for gi, (g0, gsz) in enumerate(gs):
-            self.run_group(gi, g0, gsz, n_steps, gs[gi + 1] if gi + 1 < len(gs) else None, profile_last and gi == len(gs) - 1)
-        self.flush_sr(slot=0)
+        for k, (gi, g0, gsz) in enumerate(gs):
+            self.run_group(gi, g0, gsz, n_steps, gs[k + 1] if k + 1 < len(gs) else None, profile_last and k == len(gs) - 1)
+        self.flush_sr(slot=self.flush_no & 1)
         self.drain_sr()                                # the last frames' crops are part of the timed work
+
+    def loop(self, n_steps, profile_last=False):
+        """All lanes over n_steps steps. The kernel events (profile_last) are taken on the lane that owns the LAST group: its final SR batch is
+        the drain of the pipeline, so its launches are timed without another lane's kernels sharing the CUs."""
+        lanes = [self] + self.sub
+        n_groups = len(self.groups(n_steps))
+        prof_lane = (n_groups - 1) % self.n_lanes if n_groups else 0
+        self.prof_pipe = lanes[prof_lane].pipe
+        if not self.sub:
+            return self.loop_own(n_steps, profile_last)
+        import threading
+        errs = []
+        done = [threading.Event() for _ in lanes]
+        for k, r in enumerate(lanes):
+            r._wait_for = [d for j, d in enumerate(done) if j != k] if (profile_last and k == prof_lane) else []
+
+        def work(k, r, prof):
+            try:
+                self.torch.cuda.set_device(self.dev)
+                r.loop_own(n_steps, prof)
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e)
+            finally:
+                done[k].set()
+
+        th = [threading.Thread(target=work, args=(k, r, profile_last and k == prof_lane)) for k, r in enumerate(lanes)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
 
     def barrier(self):
         import torch.distributed as dist
@@ -434,24 +494,31 @@ class Runner:
     def setup(self, warmup, steps):
         """Untimed, like loading weights: lay out, tune and graph-capture the detector plan of every group size, and the enhancer plan of
         every capacity bucket the loops will meet (a plan is keyed by capacity, not by crop sizes: a stream builds each bucket once)."""
-        for gsz in sorted({g[1] for n in (warmup, steps) for g in self.groups(n)}):
-            sf, ev = self.upload(0, self.Bl * gsz)
-            if ev is not None:
-                ev.synchronize()
-            for _ in range(3):
-                self.pipe.detect(sf, self.H, self.W, self.Bl * gsz, exchange=self.exchange, mode=self.mode)
-        self.loop(max(warmup, 2 * self.DB))
+        for r in [self] + self.sub:
+            for gsz in sorted({g[2] for n in (warmup, steps) for g in r.my_groups(n)}):
+                sf, ev = r.upload(0, r.Bl * gsz)
+                if ev is not None:
+                    ev.synchronize()
+                for _ in range(3):
+                    r.pipe.detect(sf, r.H, r.W, r.Bl * gsz, exchange=r.exchange, mode=r.mode)
+        self.loop(max(warmup, 2 * self.DB * self.n_lanes))
         if self.args.sr_crops > 0:
             self.loop(steps)                           # rehearsal with the timed loop's own crop sizes: every bucket it meets exists afterwards
-        self.sr_px = 0
+        for r in [self] + self.sub:
+            r.sr_px = 0
 
     def timed(self, warmup, steps, profile_last=True):
         import torch.distributed as dist
         self.setup(warmup, steps)
         self.loop(warmup)
         self.barrier()
-        self.sr_px = 0
-        self.tm, self.lat, self.lat_t0 = {}, [], {}
+        lanes = [self] + self.sub
+        for r in lanes:
+            r.sr_px = 0
+            r.tm, r.lat, r.lat_t0 = {}, [], {}
+            if r.jpeg_io:
+                r.jpeg_bytes_in = r.jpeg_bytes_out = 0
+                r.frames_in = 0
         t0 = time.perf_counter()
         self.loop(steps, profile_last=profile_last)
         self.barrier()
@@ -461,6 +528,18 @@ class Runner:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         self.dt_own = time.perf_counter() - t0
+        for r in self.sub:                             # one view of the run: stage times summed over the lanes' host threads, every frame's latency
+            for k, v in r.tm.items():
+                self.tm[k] = self.tm.get(k, 0.0) + v
+            self.lat += r.lat
+            self.sr_px += r.sr_px
+            if r.jpeg_io:
+                self.jpeg_bytes_in += r.jpeg_bytes_in
+                self.jpeg_bytes_out += r.jpeg_bytes_out
+                self.frames_in = getattr(self, "frames_in", 0) + getattr(r, "frames_in", 0)
+            for key in ("boxes_frame0",):
+                if key in r.state and key not in self.state:
+                    self.state[key] = r.state[key]
         return dt
 
     def report(self, steps):
@@ -517,7 +596,8 @@ def main():
     B = main_r.B
     fps = B * args.steps / dt
     main_report = main_r.report(args.steps)
-    pipe = main_r.pipe
+    pipe = main_r.prof_pipe                        # the lane that carried the kernel events of the timed loop (lane 0 when there is one lane)
+    pipes = main_r.pipes
     prof = [dict(p, stage="det") for p in pipe.det.profile()]
     if pipe.sr is not None:
         prof += [dict(p, stage="sr") for p in pipe.sr.profile()]
@@ -546,16 +626,16 @@ def main():
             try:
                 steps_r = kw.pop("steps", ss)
                 prof_sr = kw.pop("profile_sr", False)
-                r = Runner(args, ctx, pipe=pipe, **kw)
+                r = Runner(args, ctx, pipes=pipes, **kw)
                 d = r.timed(sw, steps_r, profile_last=prof_sr)
                 rep = r.report(steps_r)
                 secondary[name] = {"value": round(r.B * steps_r / d, 3), "unit": "frames/s", "ms_per_step": round(d / steps_r * 1e3, 3), "steps": steps_r, "workload": r.describe(),
-                                   "frames_per_step": r.B, "det_batch_frames": r.DB, "sr_batch_frames": r.SB, "mode": r.mode, "gathered": bool(r.state.get("gathered", False)),
+                                   "frames_per_step": r.B, "det_batch_frames": r.DB, "sr_batch_frames": r.SB, "lanes": r.n_lanes, "mode": r.mode, "gathered": bool(r.state.get("gathered", False)),
                                    "latency_ms_rank0": rep[0]["latency_ms"], "host_stage_ms_per_step_rank0": rep[0]["stage_ms_per_step"]}
                 if world > 1:
                     secondary[name]["per_rank"] = rep
-                if prof_sr and pipe.sr is not None:         # the dominant kernel at THIS row's launch sizes
-                    top = max(pipe.sr.profile(), key=lambda q: q["ms"], default=None)
+                if prof_sr and r.prof_pipe.sr is not None:         # the dominant kernel at THIS row's launch sizes
+                    top = max(r.prof_pipe.sr.profile(), key=lambda q: q["ms"], default=None)
                     if top and top["ms"] > 0:
                         ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
                         secondary[name]["roofline_dominant"] = {"kernel": top["variant"], "achieved": round(ach, 2), "peak": PEAK_TFLOPS["f16"], "unit": "TFLOP/s",
@@ -567,8 +647,14 @@ def main():
             return r
 
         # the reference's own order: strictly one frame, one SR pass at a time (docs sahi/predict.py:226,270) — nothing batched across frames
-        sec("frame_by_frame", det_batch=1, sr_batch=1, profile_sr=True)
+        sec("frame_by_frame", det_batch=1, sr_batch=1, profile_sr=True, lanes=1)      # one lane: never two frames on the card at once
         sec("steps_200", steps=200)                       # the headline configuration over a 10x longer timed region
+        if main_r.n_lanes == 1 and main_r.mode == "local":
+            # two pipeline lanes on the card: two detector + enhancer handle pairs, two host threads, detection groups dealt round-robin — the
+            # same frames, crops and seeds as the headline. Their kernels interleave (an HBM-bound 1x1 layer beside an MFMA-bound 3x3 or SR launch,
+            # a 16^2-level layer that fills half the CUs beside anything): more frames/s, but no per-kernel roofline can be read off overlapping launches
+            sec("two_lanes", lanes=2)
+            sec("two_lanes_steps_200", lanes=2, steps=200)
         sec("frames_resident_in_hbm", resident=True)
         if args.sr_crops > 0 and args.sr_sizes != "fixed":
             sec("sr_sizes_fixed", sr_sizes="fixed")
@@ -625,6 +711,13 @@ def main():
                        "span": ("frames resident in HBM -> results in host memory" if main_r.resident else
                                 "frame in pinned host memory -> upload (copy stream) -> detect -> merge -> SR -> detections + enhanced crops in host memory"),
                        "frames_per_step": B, "det_batch_frames": main_r.DB, "sr_batch_frames": main_r.SB, "mode": main_r.mode,
+                       "lanes": main_r.n_lanes,
+                       "lanes_note": ("detection groups are dealt round-robin to %d lanes (one detector + enhancer handle pair and one host thread each) whose kernels "
+                                      "interleave on the card; the kernel events behind roofline are taken on the lane that owns the last group, whose final SR batch "
+                                      "waits for the other lanes to finish and runs with the card to itself (inside the timed region); conv_profile_last_step / "
+                                      "stage_ms_last_call are that lane's last detection group WITH another lane's kernels beside it; per_rank stage times are "
+                                      "summed over the lanes' host threads"
+                                      % main_r.n_lanes) if main_r.n_lanes > 1 else None,
                        "collective": {"backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None, "ranks": world,
                                       "all_gathers_per_group": int(bool(main_state.get("gathered")))},
                        "parallelism": (f"items of {B} frame(s) in {world} contiguous cost-balanced blocks; "
@@ -643,9 +736,9 @@ def main():
             "secondary": secondary,
         }
         if world == 1 and not args.no_cpu_baseline:
-            base_r = Runner(args, ctx, pipe=pipe, resident=True)
+            base_r = Runner(args, ctx, pipes=pipes, resident=True, lanes=1)
             sf, _ = base_r.upload(0, 1)
-            d, c, _, _ = pipe.detect(sf, H, W, 1)
+            d, c, _, _ = base_r.pipe.detect(sf, H, W, 1)
             pre = torch.cat([d[k, :int(c[k])] for k in range(d.shape[0])], 0).cpu().numpy()
             boxes = main_state.get("boxes_frame0", main_state.get("boxes", np.zeros((0, 4), np.int32)))      # the crops the GPU enhanced for THIS frame (frame 0 of the timed loop)
             res["cpu_baseline"] = cpu_baseline(args, ctx["det_w"], ctx["sr_w"], ctx["host_frames"][0], boxes, pre)
