@@ -39,5 +39,15 @@ for x in det:
 print(f"total conv {tot_ms:.3f} ms for {NF} frames, algorithmic bytes {tot_b/1e9:.2f} GB -> {tot_b/tot_ms/1e9:.2f} TB/s average; graph-mode stage ms:", pipe.det.last_ms())
 flops = {x["name"].split(" ", 1)[1]: x["flops"] for x in det}
 split = 1 if "--f32" in sys.argv else 3              # MFMA products per algorithmic MAC in the split arithmetic
-for ms, name, variant, cin, cout, k, by in sorted(rows, reverse=True)[:(200 if "--all" in sys.argv else 40)]:
-    print(f"{name:34s} {variant:22s} {cin:4d}->{cout:4d} k{k} {ms*1e3:8.1f} us {by/1e6:8.1f} MB {by/ms/1e9:6.2f} TB/s  {flops[name]*split/ms/2.5e12*100:5.1f} % of 2.5 PF")
+# which roof binds a layer: its algorithmic bytes at 8 TB/s (what streams at best is 6.0-6.2, MI355X_MICROARCH.md) or its MFMA work (x3 in the split
+# arithmetic) at 2.5 PF; `of roof` = that floor / the measured time
+PEAK_BW, PEAK_MFMA = 8.0e12, 2.5e15
+sum_floor = 0.0
+shown = sorted(rows, reverse=True)
+for ms, name, variant, cin, cout, k, by in shown:
+    sum_floor += max(by / PEAK_BW, flops[name] * split / PEAK_MFMA) * 1e3
+print(f"layer-wise roofline floor (sum over layers of max(bytes / 8 TB/s, MFMA flops / 2.5 PF)): {sum_floor:.3f} ms -> the convs run at {sum_floor / tot_ms:.2f} of it")
+for ms, name, variant, cin, cout, k, by in shown[:(200 if "--all" in sys.argv else 40)]:
+    t_bw, t_mf = by / PEAK_BW * 1e3, flops[name] * split / PEAK_MFMA * 1e3
+    bound = "hbm " if t_bw >= t_mf else "mfma"
+    print(f"{name:34s} {variant:22s} {cin:4d}->{cout:4d} k{k} {ms*1e3:8.1f} us {by/1e6:8.1f} MB {by/ms/1e9:6.2f} TB/s  {flops[name]*split/ms/2.5e12*100:5.1f} % of 2.5 PF   bound {bound} {max(t_bw, t_mf) / ms:5.2f} of roof")
