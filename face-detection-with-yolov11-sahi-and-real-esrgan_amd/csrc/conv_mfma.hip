@@ -1141,7 +1141,7 @@ void launch_conv(const ConvOp& op, hipStream_t st) {
     return;
   }
   if (conv_rows_eligible(op, a)) { launch_conv_rows(a, op.out.lvl, st); FFP_HIP(hipGetLastError()); return; }
-  if (a.force_shape >= 10 && a.force_shape <= 16) {      // pointwise kernels (conv_pw.hip): only ever picked by measurement (conv_tune) or by hand
+  if ((a.force_shape >= 10 && a.force_shape <= 16) || a.force_shape == 22) {      // pointwise kernels (conv_pw.hip): only ever picked by measurement (conv_tune) or by hand
     FFP_CHECK(conv_pw_mask(op, a) & (1u << a.force_shape), FFP_ERR_ARG, "conv %s: pointwise shape %d cannot run this op", pc.name.c_str(), a.force_shape);
     launch_conv_pw(a, a.force_shape, st);
     FFP_HIP(hipGetLastError());
@@ -1185,7 +1185,7 @@ int conv_tune(const ConvOp& op, hipStream_t st) {
   };
   float best_t = 0.f, heur_t = 0.f;
   int best = -1;
-  for (int shape = 0; shape < 22; ++shape) {
+  for (int shape = 0; shape < 23; ++shape) {
     if (!(mask & (1u << shape))) continue;
     const float t1 = time_shape(shape, 2);                              // also builds the shape's tile table
     const int iters = std::min(24, std::max(3, (int)(300.f / std::max(t1, 1.f))));
@@ -1206,6 +1206,7 @@ std::string conv_variant(const ConvOp& op) {
   const ConvArgs a = make_conv_args(op);
   if (use_rows16(op, a)) return conv_rows16pc_selected(a) ? "f16_k3s1_rows16pc" : "f16_k3s1_rows16";
   if (conv_rows_eligible(op, a)) return "f16_k3s1_rows";
+  if (op.force_shape == 22) return "f32x3_k1s1_pw2x2s";
   if (op.force_shape >= 10 && op.force_shape <= 16) {
     static const char* pw[7] = {"f32x3_k1s1_pw1x4", "f32x3_k1s1_pw2x2", "f32x3_k1s1_pw2x1", "f32x3_k1s1_pw1x4w", "f32x3_k1s1_pw2x2w", "f32x3_k1s1_pw2x1w", "f32x3_k1s1_pw1x4s"};
     return pw[op.force_shape - 10];

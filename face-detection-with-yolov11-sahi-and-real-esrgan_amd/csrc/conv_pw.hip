@@ -84,20 +84,17 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
       // (64 lanes x 16 B) with 8 loads in flight; it takes part in every barrier of the consumers' schedule and does nothing else
       const int nchunks = npairs / RP;
       constexpr int PIECES = NT * CKG * 2;
+      // LDS-DMA (global_load_lds_dwordx4: global -> LDS without a register in between): the whole stage is requested at once, 64 KiB in
+      // flight instead of the 8 KiB a register batch allowed — the single producer wave was latency-bound at ~8 KiB per memory round trip
+      // and the seven consumer waves waited for it (deep layers: 27-30 % of the MFMA peak). The __syncthreads() behind every call waits
+      // for the loads (hipcc drains vmcnt at a barrier with LDS-DMA in flight) — exactly what the hand-over of the stage needs.
       auto copy_chunk = [&](int c, unsigned char* stage) {
-        uint4 buf[8];
-#pragma unroll 1
-        for (int p0 = 0; p0 < PIECES; p0 += 8) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int pc = p0 + i, nt = pc / (2 * CKG), off = (pc % (2 * CKG)) * 1024;
-            if (pc < PIECES) buf[i] = *reinterpret_cast<const uint4*>(wsrc + ((size_t)nt * ncg + (size_t)c * CKG) * 2048 + off + lane * 16);
-          }
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int pc = p0 + i, nt = pc / (2 * CKG), off = (pc % (2 * CKG)) * 1024;
-            if (pc < PIECES) *reinterpret_cast<uint4*>(stage + nt * (CKG * 2048) + off + lane * 16) = buf[i];
-          }
+        for (int pc = 0; pc < PIECES; ++pc) {
+          const int nt = pc / (2 * CKG), off = (pc % (2 * CKG)) * 1024;
+          const unsigned char* g = wsrc + ((size_t)nt * ncg + (size_t)c * CKG) * 2048 + off + lane * 16;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                           (__attribute__((address_space(3))) void*)(stage + nt * (CKG * 2048) + off), 16, 0, 0);
         }
       };
       copy_chunk(0, smem);
@@ -388,24 +385,27 @@ template <int NW, int MI, int NT, int RPMAX> struct PwShape {
   }
 };
 
-// 16: 7 consumer waves + the weight producer, 128 channels per workgroup, any K that is a multiple of 128
-struct Pw14s {
-  static constexpr int NWC = 7, RP = 4, NT = 4, LDS = 2 * NT * 2 * RP * 2048;
+// streamed weights: 7 consumer waves + the weight producer. 16: 32 px x 128 channels per wave, any K that is a multiple of 128;
+// 22: 64 px x 64 channels per wave (half the LDS fragment reads per MFMA: the deep 16^2 / 32^2 layers), any K that is a multiple of 64
+template <int MI_, int NT_, int RP_> struct PwSt {
+  static constexpr int NWC = 7, MI = MI_, RP = RP_, NT = NT_, LDS = 2 * NT * 2 * RP * 2048;
   static bool fits(const ConvArgs& a) { return a.ntiles32 % NT == 0 && (a.ncg / 2) % RP == 0; }
   static void init() {
-    FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<NWC, 1, NT, RP, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<NWC, 1, NT, RP, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<NWC, MI, NT, RP, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    FFP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<NWC, MI, NT, RP, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   }
   static void launch(ConvArgs& a, hipStream_t st) {
-    constexpr int BPX = NWC * 32;
+    constexpr int BPX = NWC * 32 * MI;
     const int pbn = (int)((a.total_px + BPX - 1) / BPX);
     a.n_nblk = a.ntiles32 / NT;
     const int nslots = std::min(pbn, std::max(1, 256 / a.n_nblk));
     if (nslots == 0) return;
-    if (a.up_c > 0) hipLaunchKernelGGL((conv_pw_kernel<NWC, 1, NT, RP, true, true>), dim3(nslots * a.n_nblk), dim3((NWC + 1) * 64), LDS, st, a);
-    else hipLaunchKernelGGL((conv_pw_kernel<NWC, 1, NT, RP, false, true>), dim3(nslots * a.n_nblk), dim3((NWC + 1) * 64), LDS, st, a);
+    if (a.up_c > 0) hipLaunchKernelGGL((conv_pw_kernel<NWC, MI, NT, RP, true, true>), dim3(nslots * a.n_nblk), dim3((NWC + 1) * 64), LDS, st, a);
+    else hipLaunchKernelGGL((conv_pw_kernel<NWC, MI, NT, RP, false, true>), dim3(nslots * a.n_nblk), dim3((NWC + 1) * 64), LDS, st, a);
   }
 };
+using Pw14s = PwSt<1, 4, 4>;
+using Pw22s = PwSt<2, 2, 2>;
 
 using Pw14 = PwShape<4, 1, 4, 4>;      // force_shape 10: 128 px x 128 ch per workgroup, K <= 160
 using Pw22 = PwShape<4, 2, 2, 2>;      // 11: 256 px x 64 ch, K <= 320
@@ -416,7 +416,7 @@ using Pw21w = PwShape<8, 2, 1, 4>;
 
 }  // namespace
 
-void conv_pw_init() { Pw14::init(); Pw22::init(); Pw21::init(); Pw14w::init(); Pw22w::init(); Pw21w::init(); Pw14s::init(); }
+void conv_pw_init() { Pw14::init(); Pw22::init(); Pw21::init(); Pw14w::init(); Pw22w::init(); Pw21w::init(); Pw14s::init(); Pw22s::init(); }
 
 // what the kernel does not do: residual inputs, fp16 outputs, input channel counts that are not whole 128-byte lines
 static bool pw_common(const ConvOp& op, const ConvArgs& a) {
@@ -436,6 +436,7 @@ unsigned conv_pw_mask(const ConvOp& op, const ConvArgs& a) {
   if (Pw22w::fits(a)) m |= 1u << 14;
   if (Pw21w::fits(a)) m |= 1u << 15;
   if (Pw14s::fits(a)) m |= 1u << 16;
+  if (Pw22s::fits(a)) m |= 1u << 22;
   return m;
 }
 
@@ -447,6 +448,7 @@ void launch_conv_pw(ConvArgs& a, int shape, hipStream_t st) {
     case 13: Pw14w::launch(a, st); break;
     case 14: Pw22w::launch(a, st); break;
     case 15: Pw21w::launch(a, st); break;
+    case 22: Pw22s::launch(a, st); break;
     default: Pw14s::launch(a, st); break;
   }
 }

@@ -190,15 +190,15 @@ def test_f32x3_scaled_split_is_fp32_grade_over_ranges(gpu_lib, name, shape):
     assert errs["f32x3"] <= 1e-5, (name, errs)
 
 
-# force_shape -> (32-channel tiles per workgroup, LDS-resident weight fragments; 0: weights streamed by a producer wave, cin a multiple of 128)
-PW_SHAPES = {10: (4, 40), 11: (2, 40), 12: (1, 40), 13: (4, 80), 14: (2, 80), 15: (1, 80), 16: (4, 0)}
+# force_shape -> (32-channel tiles per workgroup, LDS-resident weight fragments; a negative number -m: weights streamed by a producer wave, cin a multiple of m)
+PW_SHAPES = {10: (4, 40), 11: (2, 40), 12: (1, 40), 13: (4, 80), 14: (2, 80), 15: (1, 80), 16: (4, -128), 22: (2, -64)}
 
 
 def pw_can_run(shape, cin, cout):
     nt, frags = PW_SHAPES[shape]
     if (-(-cout // 32)) % nt:
         return False
-    return cin % 128 == 0 if frags == 0 else (cin % 32 == 0 and nt * (cin // 16) <= frags)
+    return cin % (-frags) == 0 if frags < 0 else (cin % 32 == 0 and nt * (cin // 16) <= frags)
 
 
 PW_CASES = [
