@@ -15,4 +15,4 @@ for n in (122, 305):
             except Exception:
                 pass
         best = min(float(r.split(":")[1]) for r in row)
-        print(f"n={n} {hw}x{hw} {cin}->{cout}: " + " ".join(row) + f"   best {best:.0f} us = {flops / best / 1e6 / 2.5e6 * 100:.0f} % of 2.5 PF", flush=True)
+        print(f"n={n} {hw}x{hw} {cin}->{cout}: " + " ".join(row) + f"   best {best:.0f} us = {flops / (best * 1e-6) / 2.5e15 * 100:.0f} % of 2.5 PF", flush=True)
