@@ -22,6 +22,10 @@
 
 #include "conv_args.hpp"
 
+#ifndef FFP_PW_STAMP
+#define FFP_PW_STAMP 0         // 1: diagnostic build — s_memtime stamps per stage of the streamed-weight form, printed by a few workgroups
+#endif
+
 namespace ffp {
 
 namespace {
@@ -219,9 +223,16 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
   wq[0][0] = *reinterpret_cast<const uint4*>(wl0);
   wq[0][1] = *reinterpret_cast<const uint4*>(wl0 + 1024);
   int it = 0;                                  // ST: chunks done so far; the current stage is it & 1
+#if FFP_PW_STAMP
+  unsigned long long stp_stream = 0, stp_barrier = 0, stp_epi = 0, stp_n = 0, stp_blk = 0, stp_nb = 0;
+  const unsigned long long stp_k0 = __builtin_amdgcn_s_memtime();
+#endif
   int run_img = -1;                            // the image this wave is collecting max |value| for, and the per-lane maximum so far
   float run_max = 0.f;
   for (; pb < pb_end; ++pb) {
+#if FFP_PW_STAMP
+    const unsigned long long stp_b0 = __builtin_amdgcn_s_memtime();
+#endif
     // this block's fragments: scale, inverse scale, image (slot index) and the end of the image's real pixels
     float ts_f[MI], ti_f[MI];
     int im_f[MI];
@@ -251,6 +262,9 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
         for (int r = 0; r < 16; ++r) acc[mi][nt][r] = 0.f;
 
     for (int kb = 0; kb < npairs; kb += RP) {
+#if FFP_PW_STAMP
+      const unsigned long long stp_t0 = __builtin_amdgcn_s_memtime();
+#endif
       const bool more = kb + RP < npairs;
       Span rs_f;
       rs_f.base = more ? rs_cur.base : rs_next.base;
@@ -303,14 +317,25 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
           __builtin_amdgcn_sched_group_barrier(0x008, 3 * MI, 0);
         }
       }
+#if FFP_PW_STAMP
+      asm volatile("s_nop 0" ::: "memory");
+      const unsigned long long stp_t1 = __builtin_amdgcn_s_memtime();
+#endif
       if constexpr (ST) {                                            // the producer has filled the other stage; everyone is done with this one
         __syncthreads();
+#if FFP_PW_STAMP
+        const unsigned long long stp_t2 = __builtin_amdgcn_s_memtime();
+        stp_stream += stp_t1 - stp_t0; stp_barrier += stp_t2 - stp_t1; ++stp_n;
+#endif
         ++it;
         wq[0][0] = *reinterpret_cast<const uint4*>(wl0 + (it & 1) * STAGE);
         wq[0][1] = *reinterpret_cast<const uint4*>(wl0 + (it & 1) * STAGE + 1024);
       }
     }
 
+#if FFP_PW_STAMP
+    const unsigned long long stp_e0 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue: register i of a tile = pixel row 8*(i>>2) + 4*hh + (i&3), this lane's channel
     const auto rs_out = rsrc(block_span(a.out, pb, a.out_cs, a.out_coff));
     const bool silu = a.act == ACT_SILU;
@@ -338,6 +363,12 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
       }
       run_max = fmaxf(run_max, am);
     }
+#if FFP_PW_STAMP
+    {
+      const unsigned long long stp_e1 = __builtin_amdgcn_s_memtime();
+      stp_epi += stp_e1 - stp_e0; stp_blk += stp_e1 - stp_b0; ++stp_nb;
+    }
+#endif
     rs_cur = rs_next;
     if constexpr (UP) {
 #pragma unroll
@@ -345,6 +376,11 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
     }
   }
   if (a.amax_out && run_img >= 0) raise_amax(a.amax_out + run_img, run_max);
+#if FFP_PW_STAMP
+  if (ST && lane == 0 && (blockIdx.x % 61) == 0 && stp_n)
+    printf("pwstamp wg %d wave %d stages %llu : stream %llu barrier %llu per stage (MFMA %d) | blocks %llu: %llu per block, epilogue %llu | kernel %llu\n", (int)blockIdx.x, wave, stp_n,
+           stp_stream / stp_n, stp_barrier / stp_n, RP * 2 * NT * 3 * MI * 32, stp_nb, stp_blk / (stp_nb ? stp_nb : 1), stp_epi / (stp_nb ? stp_nb : 1), __builtin_amdgcn_s_memtime() - stp_k0);
+#endif
 }
 
 template <int NW, int MI, int NT, int RP> struct PwCfg {
