@@ -154,3 +154,30 @@ def test_single_hip_runtime(order):
     import importlib.util
     if importlib.util.find_spec("torch") is not None:
         assert "torch" in libs            # the wheel's own copy, in both orders
+
+
+def test_bench_lanes_deal_every_group_exactly_once():
+    """bench.py --lanes L: detection groups are dealt round-robin, so the lanes together walk exactly the single-lane sequence of steps
+    (same frames, crops and seeds); the lane that owns the last group is the one whose final SR batch is event-timed."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for n_steps in (0, 1, 3, 5, 7, 20, 23, 200):
+        for db in (1, 4, 5):
+            for L in (1, 2, 3, 4):
+                lanes = []
+                for k in range(L):
+                    r = bench.Runner.__new__(bench.Runner)
+                    r.DB, r.n_lanes, r.lane = db, L, k
+                    lanes.append(r)
+                all_groups = lanes[0].groups(n_steps)
+                assert sum(g[1] for g in all_groups) == n_steps and all(0 < g[1] <= db for g in all_groups)
+                dealt = sorted(g for r in lanes for g in r.my_groups(n_steps))
+                assert [(g0, gsz) for _, g0, gsz in dealt] == all_groups and [gi for gi, _, _ in dealt] == list(range(len(all_groups)))
+                steps = sorted(s for r in lanes for _, g0, gsz in r.my_groups(n_steps) for s in range(g0, g0 + gsz))
+                assert steps == list(range(n_steps))
+                if all_groups:
+                    owner = (len(all_groups) - 1) % L
+                    assert lanes[owner].my_groups(n_steps)[-1][0] == len(all_groups) - 1
