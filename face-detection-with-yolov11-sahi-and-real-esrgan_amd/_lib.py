@@ -15,7 +15,9 @@ import numpy as np
 from . import weights_io
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libffp.so")
+# FFP_LIB=<path> loads a DIAGNOSTIC build instead (build.build_variant: in-kernel stamps, phase-skip instantiations). Probe scripts set it;
+# the shipped libffp.so is never overwritten. Nothing else changes: same symbols, same checks, it is still the only implementation.
+LIB_PATH = os.environ.get("FFP_LIB") or os.path.join(_HERE, "libffp.so")
 
 PREC_F32, PREC_F16, PREC_F32X3 = 0, 1, 2
 CHAN_AS_BGR, CHAN_AS_RGB = 0, 1

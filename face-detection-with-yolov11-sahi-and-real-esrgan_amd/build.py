@@ -66,6 +66,44 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return OUT
 
 
+# diagnostic variants: the named sources recompiled with extra defines, linked with the shipped objects into csrc/build/libffp_<name>.so.
+# Load one with FFP_LIB=<path> (_lib.py); libffp.so itself is never touched.
+VARIANTS = {
+    "pw_stamp": (["conv_pw.hip"], ["-DFFP_PW_STAMP=1"]),                    # s_memtime stamps per weight stage (profiles/r03_pw_stage_stamps.txt)
+    "r16_stamp": (["conv_rows16.hip"], ["-DFFP_R16_STAMP=1"]),              # stamps per chunk phase (profiles/r03_rows16_in_kernel_stamps.txt)
+    "r16_dbg": (["conv_rows16.hip"], ["-DFFP_R16_DBG=1"]),                  # compile-time phase-skip instantiations (tools/rows16_phase_probe.py)
+    "r16_stash1": (["conv_rows16.hip"], ["-DFFP_R16_STASH=1"]),             # staging placement experiments (tools/rows16_stash_probe.sh)
+    "r16_stash2": (["conv_rows16.hip"], ["-DFFP_R16_STASH=2"]),
+    "k3d_dbg": (["conv_k3d.hip"], ["-DFFP_K3D_DBG=1"]),
+    "trunk_dbg": (["conv_trunk.hip"], ["-DFFP_TRUNK_DBG=1"]),               # phase-skip / stamp build of the fused-trunk kernel
+}
+
+
+def build_variant(name: str, verbose: bool = True) -> str:
+    srcs, defs = VARIANTS[name]
+    build(verbose=False)                                  # the shipped objects (and libffp.so) first
+    bdir = os.path.join(CSRC, "build")
+    objs = []
+    for s_ in SOURCES:
+        base = os.path.splitext(s_)[0]
+        if s_ in srcs:
+            obj = os.path.join(bdir, f"{base}.{name}.o")
+            cmd = [_hipcc(), *FLAGS, *defs, "-c", os.path.join(CSRC, s_), "-o", obj]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {s_} ({name}):\n{r.stdout}\n{r.stderr}")
+            objs.append(obj)
+        else:
+            objs.append(os.path.join(bdir, base + ".o"))
+    out = os.path.join(bdir, f"libffp_{name}.so")
+    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {out}")
+    return out
+
+
 ASAN_SOURCES = ["common.cpp", "weights.cpp", "jpeg_dec.cpp", "asan_host_check.cpp"]
 ASAN_OUT = os.path.join(CSRC, "build", "asan_host_check")
 
@@ -93,5 +131,7 @@ def build_asan(verbose: bool = True) -> str:
 if __name__ == "__main__":
     if "--asan" in sys.argv:
         build_asan()
+    elif "--variant" in sys.argv:
+        build_variant(sys.argv[sys.argv.index("--variant") + 1])
     else:
         build(force="--force" in sys.argv)

@@ -163,7 +163,7 @@ bool conv_rows16_eligible(const ConvOp& op, const ConvArgs& a);
 void launch_conv_rows16(ConvArgs& a, const PackedConv& pc, Level* out_lvl, hipStream_t st);
 void conv_rows16_init();
 bool conv_rows16_enabled();     // FFP_ROWS16=0 keeps the first-generation kernel (A/B aid)
-// the same convs with producer / consumer waves (conv_rows16pc.hip): force_shape 24, default unless FFP_ROWS16_PC=0; bit-identical results
+// the same convs with producer / consumer waves (conv_rows16pc.hip): OPT-IN (force_shape 24 or FFP_ROWS16_PC=1; measured 0.73-0.94x); bit-identical results
 bool conv_rows16pc_selected(const ConvArgs& a);
 void launch_conv_rows16pc(ConvArgs& a, const PackedConv& pc, Level* out_lvl, hipStream_t st);
 void conv_rows16pc_init();

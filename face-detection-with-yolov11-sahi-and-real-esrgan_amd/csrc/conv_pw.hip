@@ -101,12 +101,16 @@ __global__ void __launch_bounds__((NW + (ST ? 1 : 0)) * 64, 2) conv_pw_kernel(co
                                            (__attribute__((address_space(3))) void*)(stage + nt * (CKG * 2048) + off), 16, 0, 0);
         }
       };
+      // the hand-over of a stage: the producer's LDS-DMA must have LANDED before the barrier releases the consumers. Stated here, not left
+      // to the barrier's lowering (a workgroup-scope release does not require vmcnt(0) for global operations)
       copy_chunk(0, smem);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       int it = 0;
       for (int pbp = pb_begin; pbp < pb_end; ++pbp)
         for (int c = 0; c < nchunks; ++c, ++it) {
           copy_chunk(c + 1 < nchunks ? c + 1 : 0, smem + ((it + 1) & 1) * STAGE);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
         }
       return;

@@ -766,15 +766,16 @@ void jpeg_decode_to_device(const unsigned char* data, long long n, unsigned char
     bool done = false;
     if (!host_huffman_forced()) {
       // the whole decode is queued in one go — entropy decoding (jpeg_huff.hip) and reconstruction — and checked after ONE synchronisation
-      jpeg_huff_decode_async(data, n, s, head, *ws, st);
-      jpeg_reconstruct_device(s, *ws, d_out, stride, bgr, st, false);
-      FFP_HIP(hipStreamSynchronize(st));
-      const int rc = jpeg_huff_finish(s, *ws, st);
-      if (rc == 2) {
+      if (jpeg_huff_decode_async(data, n, s, head, *ws, st)) {
         jpeg_reconstruct_device(s, *ws, d_out, stride, bgr, st, false);
         FFP_HIP(hipStreamSynchronize(st));
+        const int rc = jpeg_huff_finish(s, *ws, st);
+        if (rc == 2) {
+          jpeg_reconstruct_device(s, *ws, d_out, stride, bgr, st, false);
+          FFP_HIP(hipStreamSynchronize(st));
+        }
+        done = rc != 0;
       }
-      done = rc != 0;
       if (!done) jpeg_huff_note_fallback();
     }
     if (!done) {                                 // the host decoder: libjpeg's behaviour on damaged streams, and its error reports

@@ -56,7 +56,8 @@ void jpeg_entropy_decode(const unsigned char* data, long long n, JpegScan& out, 
 // the same Huffman decoding on the device (jpeg_huff.hip): queues everything on `st` without synchronising; after the caller's
 // synchronisation jpeg_huff_finish returns 1 (coefficient planes ws.dev[] are right), 2 (right after further rounds: run the
 // reconstruction again) or 0 (the stream needs the host decoder: damaged data, or something libjpeg treats specially)
-void jpeg_huff_decode_async(const unsigned char* data, long long n, const JpegScan& s, const JpegHead& head, JpegDecodeWs& ws, hipStream_t st);
+// returns false, with nothing queued, for a file outside this decoder's limits (a scan of 256 MiB or more, more than six blocks per MCU)
+bool jpeg_huff_decode_async(const unsigned char* data, long long n, const JpegScan& s, const JpegHead& head, JpegDecodeWs& ws, hipStream_t st);
 int jpeg_huff_finish(const JpegScan& s, JpegDecodeWs& ws, hipStream_t st);
 void jpeg_huff_stats(long long* device_decodes, long long* host_fallbacks, long long* extra_sync_rounds);
 void jpeg_huff_note_fallback();

@@ -274,6 +274,14 @@ __device__ __forceinline__ void decode_run(const HuffLds& L, unsigned bit0, cons
   int nblk = 0, dc[3] = {0, 0, 0};
   int pred[3] = {cnt.y, cnt.z, cnt.w};          // WRITE: predictors at entry come in through cnt
   int e = 0;
+  // An adopted entry state can sit BELOW the workgroup's window base (the previous workgroup's last thread stopped early at the end of a
+  // segment whose final subsequence is shorter than a word): p - bit0 would wrap and index far outside L.words. Such a state decodes
+  // nothing here — it is handed on unchanged and flagged, so that a stream that ends up relying on it goes to the host decoder.
+  if (p < bit0) {
+    cnt = make_int4(0, WRITE ? cnt.y : 0, WRITE ? cnt.z : 0, WRITE ? cnt.w : 0);
+    if (WRITE && err) *err = E_PHASE;
+    return;
+  }
   unsigned wi = (p - bit0) >> 5;
   unsigned long long acc = L.words[wi++];
   int nb = 32 - (int)((p - bit0) & 31u);
@@ -513,11 +521,18 @@ void zero_planes(const JpegScan& s, JpegDecodeWs& ws, hipStream_t st) {
 // Queues the whole entropy decode of the scan on `st` (coefficient planes: ws.dev[c]) under the assumption that ONE round of
 // synchronisation across workgroups is enough — it practically always is; jpeg_huff_finish() checks after the caller's
 // synchronisation. Nothing is synchronised here.
-void jpeg_huff_decode_async(const unsigned char* data, long long n, const JpegScan& s, const JpegHead& head, JpegDecodeWs& ws, hipStream_t st) {
+bool jpeg_huff_decode_async(const unsigned char* data, long long n, const JpegScan& s, const JpegHead& head, JpegDecodeWs& ws, hipStream_t st) {
+  // limits of THIS decoder are not errors of the file: 32-bit bit offsets (a scan + trailer of 256 MiB or more) and six blocks per MCU.
+  // The caller then takes the host decoder, as round 2 did for every file.
+  const long long n_raw = n - head.data_off;
+  if (n_raw <= 0 || n_raw >= (1ll << 28)) return false;
+  {
+    int bpm = 0;
+    for (int c = 0; c < s.ncomp; ++c) bpm += s.comp[c].hs * s.comp[c].vs;
+    if (bpm > 6) return false;
+  }
   if (!ws.huff) ws.huff = new JpegHuffWs();
   JpegHuffWs& H = *ws.huff;
-  const long long n_raw = n - head.data_off;
-  FFP_CHECK(n_raw > 0 && n_raw < (1ll << 28), FFP_ERR_ARG, "jpeg: entropy-coded segment of %lld bytes", n_raw);     // bit offsets are 32-bit
   HuffParams P;
   std::memset(&P, 0, sizeof(P));
   P.ncomp = s.ncomp;
@@ -580,6 +595,7 @@ void jpeg_huff_decode_async(const unsigned char* data, long long n, const JpegSc
   hipLaunchKernelGGL(jh_sync_kernel<true>, dim3(H.sub_wgs), dim3(NT), 0, st, b, P);
   hipLaunchKernelGGL(jh_sync_kernel<false>, dim3(H.sub_wgs), dim3(NT), 0, st, b, P);
   queue_scan_and_write(H, s, ws, st);
+  return true;
 }
 
 // After the stream has been synchronised: 1 = the coefficient planes are right; 2 = they are right NOW, after more rounds of

@@ -199,3 +199,69 @@ def test_spread_group_one_gather_per_group(world, n_frames):
         rows = np.concatenate([exp[k, :expc[k]] for k in range(s0, s0 + ns)], 0)
         ref_rows = np.concatenate([fake_item_dets(i, items[i])[0][:fake_item_dets(i, items[i])[1]] for i in range(f * L.ipf, (f + 1) * L.ipf)], 0)
         assert np.array_equal(rows, ref_rows)
+
+
+def _worker_spread8(rank, world, port, n_frames, q):
+    """The BASELINE config-4 shape on CPU: 4K frames, 512 / 0.2 slices (61 items per frame), 5-frame detection groups over 8 ranks."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = pipeline.PipeConfig()
+        items = pipeline.frame_items(2160, 3840, cfg, n_frames)
+        L = pipeline.Layout(items, n_frames, world, pipeline.item_costs(items, cfg.imgsz), spread=True)
+        mine = L.local_items(rank)
+        lo, hi = L.frame_bounds[rank]
+        b = hi - lo
+        local = torch.zeros((L.local_slots(), MAX_DET, STRIDE))
+        counts = torch.zeros((L.local_slots(),), dtype=torch.int32)
+        for k in range(len(mine)):
+            f, j = divmod(k, b)
+            i = f * L.ipf + lo + j
+            d, n = fake_item_dets(i, items[i])
+            local[f * L.per + j] = torch.from_numpy(d)
+            counts[f * L.per + j] = n
+        g, gc = pipeline.exchange_detections(local, counts, world)
+        g, gc = pipeline.frame_major(g, gc, world, n_frames, L.per)
+        sizes = pipeline.sr_crop_sizes(32, seed=1000).astype(np.int64)
+        own = pipeline.lpt_assign(sizes ** 2, world) == rank                # this rank's crops of frame 0
+        q.put((rank, int(gc.sum()), float(g.double().sum()), int(own.sum()), int((sizes[own] ** 2).sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_spread_world8_five_frame_groups():
+    """VERDICT r3 item 9 — insurance for the day an 8-GPU node runs `--frames-per-step 1`: world 8, 5-frame groups, 61 items per 4K frame.
+    Slot order, padding, one gather per group, cost balance of the contiguous blocks and of the LPT crop placement."""
+    world, n_frames = 8, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_spread8, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cfg = pipeline.PipeConfig()
+    items = pipeline.frame_items(2160, 3840, cfg, n_frames)
+    costs = pipeline.item_costs(items, cfg.imgsz)
+    L = pipeline.Layout(items, n_frames, world, costs, spread=True)
+    assert L.ipf == 61 and len(items) == 305
+    fb = L.frame_bounds
+    assert [b[0] for b in fb] + [61] == [0] + [b[1] for b in fb]          # contiguous, complete
+    assert L.per == 8 and L.local_slots() == 40                            # 8 slots per frame and rank: 8 x 5 x 8 x 25 KB = 8 MB per gather at max_det 300
+    blk = np.asarray([costs[lo:hi].sum() for lo, hi in fb]) / (512 * 512)
+    assert blk.max() <= 8.0 and blk.max() / blk.mean() <= 1.10, blk       # heaviest block within 10 % of the mean (60.56 slice units / 8 = 7.57)
+    assert sorted(hi - lo for lo, hi in fb) == [5] + [8] * 7              # the last rank: 4 slices + the full-frame pass
+    slots = [L.slot(i) for i in range(len(items))]
+    assert slots == sorted(slots) and len(set(slots)) == len(slots) and max(slots) < n_frames * world * L.per
+    tot_n = sum(fake_item_dets(i, items[i])[1] for i in range(len(items)))
+    tot_v = sum(float(fake_item_dets(i, items[i])[0].astype(np.float64).sum()) for i in range(len(items)))
+    for r, n, v, _, _ in got:                                              # every rank holds every frame's detections after ONE gather
+        assert n == tot_n and abs(v - tot_v) < 1e-3 * max(1.0, abs(tot_v)), (r, n, tot_n)
+    sizes = pipeline.sr_crop_sizes(32, seed=1000).astype(np.int64)
+    assert sum(g[3] for g in got) == 32 and sum(g[4] for g in got) == int((sizes ** 2).sum())       # every crop placed exactly once
+    loads = np.asarray([g[4] for g in got], np.float64)
+    assert loads.max() <= loads.mean() + (sizes ** 2).max()               # LPT bound

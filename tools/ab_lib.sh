@@ -1,16 +1,18 @@
 #!/bin/bash
-# A/B two builds of libffp.so inside ONE gpurun call: <pkg>/libffp.so (A) vs <pkg>/libffp_B.so (B). Optional: a probe script run under both.
-P=face-detection-with-yolov11-sahi-and-real-esrgan_amd
-cp $P/libffp.so $P/libffp_A.so
+# A/B of two builds of the library in ONE gpurun call (same box): A = the shipped libffp.so, B = $FFP_LIB_B (a second build, e.g.
+# csrc/build/libffp_<variant>.so or a copy made before an edit). Each side is loaded through FFP_LIB — libffp.so is never overwritten.
+# usage: FFP_LIB_B=path tools/ab_lib.sh [probe.py]
+set -euo pipefail
+: "${FFP_LIB_B:?set FFP_LIB_B to the second library}"
+mkdir -p gpurun_out
 for r in 1 2; do
-  cp $P/libffp_A.so $P/libffp.so; timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/ab_A$r.json 2>/dev/null
-  cp $P/libffp_B.so $P/libffp.so; timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/ab_B$r.json 2>/dev/null
+  timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/ab_A$r.json 2>/dev/null
+  FFP_LIB=$FFP_LIB_B timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/ab_B$r.json 2>/dev/null
 done
-if [ -n "$1" ]; then
-  cp $P/libffp_A.so $P/libffp.so; timeout -k 10 200 python $1 > gpurun_out/ab_probe_A.txt 2>&1
-  cp $P/libffp_B.so $P/libffp.so; timeout -k 10 200 python $1 > gpurun_out/ab_probe_B.txt 2>&1
+if [ -n "${1:-}" ]; then
+  timeout -k 10 200 python "$1" > gpurun_out/ab_probe_A.txt 2>&1
+  FFP_LIB=$FFP_LIB_B timeout -k 10 200 python "$1" > gpurun_out/ab_probe_B.txt 2>&1
 fi
-cp $P/libffp_A.so $P/libffp.so
 python - <<'PY'
 import json
 for n in ("A1", "B1", "A2", "B2"):

@@ -1,6 +1,10 @@
-# Diagnostic: build libffp_stamp.so first (conv_pw.hip with -DFFP_PW_STAMP=1, linked with the other objects) — see profiles/r03_pw_stage_stamps.txt
+#!/bin/bash
+# Diagnostic: conv_pw.hip with -DFFP_PW_STAMP=1 (python -m ffp_amd.build --variant pw_stamp, built HERE before gpurun), loaded through
+# FFP_LIB — the shipped libffp.so is never overwritten. See profiles/r03_pw_stage_stamps.txt
+set -euo pipefail
 P=face-detection-with-yolov11-sahi-and-real-esrgan_amd
-cp $P/libffp.so /tmp/libffp_keep.so; cp $P/libffp_stamp.so $P/libffp.so
+export FFP_LIB=$PWD/$P/csrc/build/libffp_pw_stamp.so
+test -f "$FFP_LIB" || { echo "build it first: python -c 'import ffp_amd.build as b; b.build_variant(\"pw_stamp\")'"; exit 1; }
 timeout -k 10 120 python - <<'PY'
 import os, sys
 sys.path.insert(0, os.getcwd())
@@ -10,4 +14,3 @@ for n, hw, cin, cout in ((305, 16, 1024, 512), (305, 16, 512, 512)):
     us = _lib.op_conv2d_time(n, hw, hw, cin, cout, 1, 1, False, _lib.PREC_F32X3, 2, 0, 16)
     print(f"== n={n} {hw}x{hw} {cin}->{cout} pw1x4s: {us:.0f} us", flush=True)
 PY
-cp /tmp/libffp_keep.so $P/libffp.so

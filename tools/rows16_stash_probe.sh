@@ -1,7 +1,10 @@
+#!/bin/bash
+# Staging-placement experiment of conv_rows16_kernel: variants r16_stash1 / r16_stash2 (build.build_variant, built HERE before gpurun) against
+# the shipped library, each loaded through FFP_LIB — libffp.so is never overwritten. See profiles/r03_rows16_stash_placement_probe.txt
+set -euo pipefail
 P=face-detection-with-yolov11-sahi-and-real-esrgan_amd
-cp $P/libffp.so /tmp/libffp_s0.so; cp $P/libffp_s1.so /tmp/; cp $P/libffp_s2.so /tmp/
 for v in 0 1 2; do
-  cp /tmp/libffp_s$v.so $P/libffp.so
+  if [ $v = 0 ]; then unset FFP_LIB; else export FFP_LIB=$PWD/$P/csrc/build/libffp_r16_stash$v.so; test -f "$FFP_LIB" || { echo "missing $FFP_LIB"; exit 1; }; fi
   echo "== stash variant $v"
   timeout -k 10 120 python - <<'PY'
 import os, sys
@@ -15,4 +18,3 @@ for n, cin, cout in ((2048, 128, 32), (2048, 64, 32), (2048, 192, 64), (4700, 16
 PY
   timeout -k 10 300 python bench.py --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench', r['value'], r['ms_per_step'], r['roofline']['frac'], r['roofline']['avg_launch_us'])"
 done
-cp /tmp/libffp_s0.so $P/libffp.so
