@@ -152,10 +152,16 @@ class Runner:
     """One configuration of the hot path: its pipeline, its resident plans, its timed loop."""
 
     def __init__(self, args, ctx, *, det_precision=None, imgsz=None, pp_type=None, class_agnostic=None, sr_sizes=None, frames_per_step=None,
-                 exchange=None, resident=None, pipe=None, pipes=None, det_batch=None, sr_batch=None, jpeg_io=False, lanes=None, _lane=0, _n_lanes=None):
+                 exchange=None, resident=None, pipe=None, pipes=None, det_batch=None, sr_batch=None, jpeg_io=False, lanes=None, workload=None,
+                 verify=False, _lane=0, _n_lanes=None):
         import torch
         kw = dict(det_precision=det_precision, imgsz=imgsz, pp_type=pp_type, class_agnostic=class_agnostic, sr_sizes=sr_sizes, frames_per_step=frames_per_step,
-                  exchange=exchange, resident=resident, det_batch=det_batch, sr_batch=sr_batch, jpeg_io=jpeg_io)
+                  exchange=exchange, resident=resident, det_batch=det_batch, sr_batch=sr_batch, jpeg_io=jpeg_io, workload=workload, verify=verify)
+        if workload:                                  # another BASELINE config: its own frame size / tiling / crop count (and its own synthetic frames, in ctx)
+            args = argparse.Namespace(**{**vars(args), **workload})
+        self.verify = verify
+        self.rec = {}                                 # verify: per frame id -> what the pipelined loop produced for it
+        self.own_pipe = False
         if pipes is None and pipe is not None:
             pipes = [pipe]
         pipe = pipes[_lane] if pipes is not None and _lane < len(pipes) else None
@@ -201,6 +207,7 @@ class Runner:
             self.pipe = pipeline.FramePipeline(ctx["det_w"], ctx["sr_w"], self.cfg, arch=args.arch, device=ctx["local_rank"],
                                                det_precision={"f16": _lib.PREC_F16, "f32x3": _lib.PREC_F32X3, "f32": _lib.PREC_F32}[self.det_precision],
                                                sr_half=True, rank=self.rank, world=self.world)
+            self.own_pipe = True
         self.items_per_frame = pipeline.frame_items(self.H, self.W, self.cfg, 1).shape[0]
         self.fixed_sizes = pipeline.sr_crop_sizes(max(args.sr_crops, 1), seed=0)
         self.host_rows = torch.empty((self.cfg.merge_cap, self.pipe.stride), dtype=torch.float32).pin_memory()
@@ -229,6 +236,32 @@ class Runner:
             self.sub = [Runner(args, ctx, pipes=pipes, _lane=k, _n_lanes=self.n_lanes, **kw) for k in range(1, self.n_lanes)]
         self.pipes = [self.pipe] + [r.pipe for r in self.sub]
         self.prof_pipe = self.pipe                     # the lane whose last group / SR batch carries the kernel events (loop())
+
+    def close(self):
+        """Release what this configuration holds on the device and in pinned memory (a secondary row must not leave its plans behind:
+        round 3's four-ranks-on-one-GPU rehearsal ran out of memory in the later rows)."""
+        for r in self.sub:
+            r.close()
+        self.torch.cuda.synchronize(self.dev)
+        if self.own_pipe:
+            self.pipe.det.close()
+            if self.pipe.sr is not None:
+                self.pipe.sr.close()
+            self.pipe._bufs.clear()
+        self.slots.clear(); self.host_supers.clear(); self.pending.clear(); self.queue.clear(); self.group.clear(); self.rec.clear()
+        self.host_sr = None
+        self.torch.cuda.empty_cache()
+
+    def mem(self):
+        """Device bytes the lanes' handles hold: packed weights + resident plans (ffp_det_mem_bytes / ffp_sr_mem_bytes)."""
+        out = {"det_weights": 0, "det_plans": 0, "det_plans_resident": 0, "sr_weights": 0, "sr_plans": 0, "sr_plans_resident": 0}
+        for p in {id(q): q for q in self.pipes}.values():
+            d = p.det.mem_bytes()
+            out["det_weights"] += d["weights"]; out["det_plans"] += d["plans"]; out["det_plans_resident"] += d["plans_resident"]
+            if p.sr is not None:
+                e = p.sr.mem_bytes()
+                out["sr_weights"] += e["weights"]; out["sr_plans"] += e["plans"]; out["sr_plans_resident"] += e["plans_resident"]
+        return out
 
     # ---- frames: pinned host super-frames, three device slots per super-frame size, uploads on a copy stream ----------------
     def frame_of(self, variant, f):
@@ -626,12 +659,25 @@ def main():
             try:
                 steps_r = kw.pop("steps", ss)
                 prof_sr = kw.pop("profile_sr", False)
-                r = Runner(args, ctx, pipes=pipes, **kw)
+                ctx_r, share = ctx, pipes
+                wl = kw.get("workload")
+                if wl:                                   # another BASELINE config: its own weights / frames, nothing shared with the headline's handles
+                    ctx_r, share = dict(ctx), None
+                    if wl.get("arch", args.arch) != args.arch:
+                        ctx_r["det_w"] = synth.yolo11_pose_weights(wl["arch"])
+                    if (wl.get("height", H), wl.get("width", W)) != (H, W):
+                        assert (wl["height"], wl["width"]) == (2 * H, 2 * W), "workload frames are 2 x 2 mosaics of the headline's synthetic frames"
+                        hf = ctx["host_frames"]
+                        ctx_r["host_frames"] = [np.ascontiguousarray(np.concatenate([np.concatenate([hf[i], hf[(i + 1) % len(hf)]], 1),
+                                                                                     np.concatenate([hf[(i + 1) % len(hf)], hf[i]], 1)], 0)) for i in range(len(hf))]
+                    if wl.get("sr_crops", args.sr_crops) > 0 and ctx_r["sr_w"] is None:
+                        ctx_r["sr_w"] = synth.rrdbnet_weights(4, 23)
+                r = Runner(args, ctx_r, pipes=share, **kw)
                 d = r.timed(sw, steps_r, profile_last=prof_sr)
                 rep = r.report(steps_r)
                 secondary[name] = {"value": round(r.B * steps_r / d, 3), "unit": "frames/s", "ms_per_step": round(d / steps_r * 1e3, 3), "steps": steps_r, "workload": r.describe(),
                                    "frames_per_step": r.B, "det_batch_frames": r.DB, "sr_batch_frames": r.SB, "lanes": r.n_lanes, "mode": r.mode, "gathered": bool(r.state.get("gathered", False)),
-                                   "latency_ms_rank0": rep[0]["latency_ms"], "host_stage_ms_per_step_rank0": rep[0]["stage_ms_per_step"]}
+                                   "latency_ms_rank0": rep[0]["latency_ms"], "host_stage_ms_per_step_rank0": rep[0]["stage_ms_per_step"], "hbm_bytes": r.mem()}
                 if world > 1:
                     secondary[name]["per_rank"] = rep
                 if prof_sr and r.prof_pipe.sr is not None:         # the dominant kernel at THIS row's launch sizes
@@ -644,6 +690,9 @@ def main():
             except Exception as e:      # noqa: BLE001
                 secondary[name] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
                 print(f"[bench] secondary row {name} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            finally:
+                if r is not None:
+                    r.close()                          # a row's own handles, slots and pinned buffers go before the next row is built
             return r
 
         # the reference's own order: strictly one frame, one SR pass at a time (docs sahi/predict.py:226,270) — nothing batched across frames
@@ -656,6 +705,11 @@ def main():
             sec("two_lanes", lanes=2)
             sec("two_lanes_steps_200", lanes=2, steps=200)
         sec("frames_resident_in_hbm", resident=True)
+        if world == 1:
+            # the other BASELINE configs on the final tree (config 3 is the headline; 4 and the 8-GPU part of 5 need the driver's node)
+            sec("config2_detect_only", workload={"sr_crops": 0})           # single 4K image, YOLO11s, SAHI 512 / 0.2, no SR
+            sec("config5_8k_640_one_gpu", workload={"height": 2 * H, "width": 2 * W, "slice": 640, "overlap": 0.25, "imgsz": 640, "sr_crops": 128},
+                imgsz=640, det_batch=2, sr_batch=2, steps=min(ss, 8), lanes=1)   # 8K frame, 640 / 0.25 (144 slices + full frame), x4 SR on 128 crops: the one-GPU shape of config 5
         if args.sr_crops > 0 and args.sr_sizes != "fixed":
             sec("sr_sizes_fixed", sr_sizes="fixed")
         sec("merge_nms_ios_agnostic", pp_type="NMS", class_agnostic=True)

@@ -86,6 +86,9 @@ _SIGS = {
                                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, _p(C.c_int64)]),
     "ffp_sr_plan_state": (C.c_int, [C.c_void_p, _p(C.c_int32), _p(C.c_int32)]),
     "ffp_det_graph_status": (C.c_int, [C.c_void_p, _p(C.c_int32)]),
+    "ffp_sr_set_fused_body": (C.c_int, [C.c_void_p, C.c_int]),
+    "ffp_sr_mem_bytes": (C.c_int, [C.c_void_p, _p(C.c_uint64), _p(C.c_uint64), _p(C.c_int32)]),
+    "ffp_det_mem_bytes": (C.c_int, [C.c_void_p, _p(C.c_uint64), _p(C.c_uint64), _p(C.c_int32)]),
     "ffp_det_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),
     "ffp_det_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ffp_sr_last_ms": (C.c_int, [C.c_void_p, _p(C.c_float)]),
@@ -290,6 +293,12 @@ class Detector:
         _check(lib().ffp_det_graph_status(self._h, C.byref(v)))
         return v.value
 
+    def mem_bytes(self) -> dict:
+        """Device memory held: packed weights, resident plans (activations + tables), number of plans."""
+        a, b, n = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
+        _check(lib().ffp_det_mem_bytes(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return {"weights": int(a.value), "plans": int(b.value), "plans_resident": int(n.value)}
+
     def set_lanes(self, mode: int):
         """0 (default) one stream; 1 head towers and C3k side convs as parallel graph branches (detector-only deployments)."""
         _check(lib().ffp_det_set_lanes(self._h, int(mode)))
@@ -418,6 +427,15 @@ class Enhancer:
         v = C.c_float(0)
         _check(lib().ffp_sr_last_ms(self._h, C.byref(v)))
         return v.value
+
+    def set_fused_body(self, on: bool):
+        """The 345 body convs as ONE persistent launch (default in fp16) or one launch per layer; bit-identical results (drops the plans)."""
+        _check(lib().ffp_sr_set_fused_body(self._h, int(on)))
+
+    def mem_bytes(self) -> dict:
+        a, b, n = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
+        _check(lib().ffp_sr_mem_bytes(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return {"weights": int(a.value), "plans": int(b.value), "plans_resident": int(n.value)}
 
     def plan_state(self) -> dict:
         """plans_built: network layouts built so far (capacity-keyed: varying crop sizes must not grow it);

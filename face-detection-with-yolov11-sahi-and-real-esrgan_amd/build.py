@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libffp.so")
-SOURCES = ["common.cpp", "weights.cpp", "engine.cpp", "conv_mfma.hip", "conv_rows.hip", "conv_rows16.hip", "conv_rows16pc.hip", "conv_pw.hip", "conv_k3d.hip", "ops_misc.hip", "det_post.hip", "merge.hip", "eval.hip", "jpeg.hip", "jpeg_huff.hip", "jpeg_dec.cpp",
+SOURCES = ["common.cpp", "weights.cpp", "engine.cpp", "conv_mfma.hip", "conv_rows.hip", "conv_rows16.hip", "conv_rows16pc.hip", "conv_trunk.hip", "conv_pw.hip", "conv_k3d.hip", "ops_misc.hip", "det_post.hip", "merge.hip", "eval.hip", "jpeg.hip", "jpeg_huff.hip", "jpeg_dec.cpp",
            "sr_ops.hip", "yolo11.cpp", "rrdb.cpp", "api.cpp"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result",
          "-ffp-contract=off"]

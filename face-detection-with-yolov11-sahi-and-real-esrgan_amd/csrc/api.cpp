@@ -470,6 +470,29 @@ int ffp_sr_plan_state(ffp_sr* s, int32_t* out_plans_built, int32_t* out_last_gra
   return FFP_OK;
 }
 
+int ffp_sr_set_fused_body(ffp_sr* s, int on) {
+  FFP_API_BEGIN
+  FFP_CHECK(s, FFP_ERR_ARG, "null handle");
+  s->eng.set_fused_body(on != 0);
+  FFP_API_END
+}
+
+int ffp_sr_mem_bytes(ffp_sr* s, uint64_t* out_weight_bytes, uint64_t* out_plan_bytes, int32_t* out_plans_resident) {
+  if (!s) return FFP_ERR_ARG;
+  if (out_weight_bytes) *out_weight_bytes = s->eng.weight_bytes();
+  if (out_plan_bytes) *out_plan_bytes = s->eng.plan_bytes();
+  if (out_plans_resident) *out_plans_resident = s->eng.plans_resident();
+  return FFP_OK;
+}
+
+int ffp_det_mem_bytes(ffp_det* d, uint64_t* out_weight_bytes, uint64_t* out_plan_bytes, int32_t* out_plans_resident) {
+  if (!d) return FFP_ERR_ARG;
+  if (out_weight_bytes) *out_weight_bytes = d->eng.weight_bytes();
+  if (out_plan_bytes) *out_plan_bytes = d->eng.plan_bytes();
+  if (out_plans_resident) *out_plans_resident = d->eng.plans_resident();
+  return FFP_OK;
+}
+
 int ffp_sr_last_ms(ffp_sr* s, float* out_ms) { if (!s || !out_ms) return FFP_ERR_ARG; *out_ms = s->eng.last_ms; return FFP_OK; }
 int ffp_sr_last_conv_stats(ffp_sr* s, double* out_flops, float* out_ms, int32_t* out_launches) {
   if (!s) return FFP_ERR_ARG;
@@ -865,11 +888,15 @@ int ffp_op_conv2d_time(int device, int precision, int n, int h, int w, int cin, 
     o.pc = &pc; o.stride = stride; o.act = precision == FFP_PREC_F16 ? ACT_LRELU : ACT_SILU; o.up = up; o.dbg = dbg_mask; o.force_shape = force_shape;   // the activation each precision's network uses
     o.in = TView{din.p, T, pc.cin, 0, pc.cin, &lin};
     o.out = TView{dout.p, T, cout, 0, cout, &lout};
-    for (int i = 0; i < 3; ++i) launch_conv(o, st);
+    // force_shape 25: the fused-body kernel (conv_trunk.hip) on this ONE layer, its plan built once outside the timed launches
+    std::unique_ptr<TrunkPlan> tp;
+    if (force_shape == 25) tp.reset(new TrunkPlan(std::vector<ConvOp>{o}));
+    auto once = [&]() { if (tp) tp->launch(st, dbg_mask); else launch_conv(o, st); };
+    for (int i = 0; i < 3; ++i) once();
     hipEvent_t e0, e1;
     FFP_HIP(hipEventCreate(&e0)); FFP_HIP(hipEventCreate(&e1));
     FFP_HIP(hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) launch_conv(o, st);
+    for (int i = 0; i < iters; ++i) once();
     FFP_HIP(hipEventRecord(e1, st));
     FFP_HIP(hipStreamSynchronize(st));
     float ms = 0.f;

@@ -64,6 +64,9 @@ void Level::reserve(int cap_n, int64_t cap_px, int cap_tiles16, hipStream_t st) 
   FFP_HIP(hipHostMalloc(&stage, stage_bytes, hipHostMallocDefault));
 }
 
+// 4th component of a tile entry: the image's tile grid, columns | rows << 16 (conv_trunk.hip finds a tile's neighbours with it)
+static inline int tile_grid(int h, int w, int th) { return ((w + 15) / 16) | (((h + th - 1) / th) << 16); }
+
 void Level::fill_tiles(int th, TileTab& t, hipStream_t st, size_t* stage_off) {
   // capacity mode: tile rows of the current batch -> staging -> device (only the real entries; kernels bound on d_count)
   int4* dst = reinterpret_cast<int4*>(static_cast<unsigned char*>(stage) + *stage_off);
@@ -72,7 +75,7 @@ void Level::fill_tiles(int th, TileTab& t, hipStream_t st, size_t* stage_off) {
     for (int y = 0; y < h[i]; y += th)
       for (int x = 0; x < w[i]; x += 16) {
         FFP_CHECK(k < t.cap, FFP_ERR_STATE, "level: batch needs more than %d tiles of height %d", t.cap, th);
-        dst[k++] = make_int4(i, y, x, 0);
+        dst[k++] = make_int4(i, y, x, tile_grid(h[i], w[i], th));
       }
   dst[k] = make_int4(k, 0, 0, 0);          // the count travels right behind the entries
   t.n = k;
@@ -156,7 +159,7 @@ const int4* Level::tile_table(int th, int* n_launch, const int** d_count, hipStr
       std::vector<int4> v;
       for (int i = 0; i < act_n; ++i)
         for (int y = 0; y < h[i]; y += th)
-          for (int x = 0; x < w[i]; x += 16) v.push_back(make_int4(i, y, x, 0));
+          for (int x = 0; x < w[i]; x += 16) v.push_back(make_int4(i, y, x, tile_grid(h[i], w[i], th)));
       FFP_CHECK((int)v.size() <= t.cap, FFP_ERR_STATE, "level: batch needs more than %d tiles of height %d", t.cap, th);
       t.n = (int)v.size();
       if (t.n > 0) FFP_HIP(hipMemcpyAsync(t.tab.p, v.data(), sizeof(int4) * v.size(), hipMemcpyHostToDevice, st));
@@ -166,7 +169,7 @@ const int4* Level::tile_table(int th, int* n_launch, const int** d_count, hipStr
       std::vector<int4> v;
       for (int i = 0; i < n; ++i)
         for (int y = 0; y < h[i]; y += th)
-          for (int x = 0; x < w[i]; x += 16) v.push_back(make_int4(i, y, x, 0));
+          for (int x = 0; x < w[i]; x += 16) v.push_back(make_int4(i, y, x, tile_grid(h[i], w[i], th)));
       t.tab.alloc(sizeof(int4) * v.size());
       FFP_HIP(hipMemcpyAsync(t.tab.p, v.data(), sizeof(int4) * v.size(), hipMemcpyHostToDevice, st));
       FFP_HIP(hipStreamSynchronize(st));

@@ -93,7 +93,7 @@ struct HostPinned {
 // entries of the image table are {total actual pixels, 0, 0} so flat-pixel kernels drop the pixels past the batch, and
 // tile kernels read the actual tile count from device memory (TileTab::d_count).
 struct TileTab {
-  DevBuf tab;        // int4 {img, y0, x0, 0}
+  DevBuf tab;        // int4 {img, y0, x0, tile columns | tile rows << 16 of the image}
   DevBuf d_count;    // int[1]: tiles of the current batch (what the kernels loop / bound on in capacity mode)
   int n = 0;         // tiles of the current batch
   int cap = 0;       // capacity mode: table capacity == launch extent

@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "conv_args.hpp"
+#include "trunk.hpp"
 #include "letterbox.hpp"
 
 #ifndef FFP_SINGLE_STAGE
@@ -1029,6 +1030,7 @@ void conv_kernels_init() {
   conv_rows_init();
   conv_rows16_init();
   conv_rows16pc_init();
+  conv_trunk_init();
   conv_pw_init();
   conv_k3d_init();
   Family<float, 1, 1>::init(); Family<float, 3, 1>::init(); Family<float, 3, 2>::init();
@@ -1134,6 +1136,13 @@ void launch_conv(const ConvOp& op, hipStream_t st) {
   const PackedConv& pc = *op.pc;
   if (conv_direct_eligible(op)) { launch_conv_direct(op, st); return; }
   ConvArgs a = make_conv_args(op);
+  if (a.force_shape == 25) {                     // the fused-body kernel on ONE layer (tests, probes): a throw-away single-layer plan
+    FFP_CHECK(conv_trunk_layer_ok(op), FFP_ERR_ARG, "conv %s: not a layer conv_trunk_kernel can run", pc.name.c_str());
+    TrunkPlan tp(std::vector<ConvOp>{op});
+    tp.launch(st, op.dbg);
+    FFP_HIP(hipStreamSynchronize(st));           // the plan's tables die with it
+    return;
+  }
   if (use_rows16(op, a)) {
     if (conv_rows16pc_selected(a)) launch_conv_rows16pc(a, pc, op.out.lvl, st);
     else launch_conv_rows16(a, pc, op.out.lvl, st);

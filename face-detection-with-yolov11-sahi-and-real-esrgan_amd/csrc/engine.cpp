@@ -62,10 +62,17 @@ Level* Plan::add_level_capacity(int cap_n, int64_t cap_px, int cap_t16, hipStrea
   return levels.back().get();
 }
 
+double Step::actual_flops() const {
+  if (!is_conv) return 0;
+  if (!trunk) return conv_flops_of(*conv->pc, conv->out.lvl->actual_px());
+  double f = 0;
+  for (const auto& c : fused) f += conv_flops_of(*c->pc, c->out.lvl->actual_px());
+  return f;
+}
+
 double Plan::actual_conv_flops() const {
   double f = 0;
-  for (const Step& s : steps)
-    if (s.is_conv) f += conv_flops_of(*s.conv->pc, s.conv->out.lvl->actual_px());
+  for (const Step& s : steps) f += s.actual_flops();
   return f;
 }
 
@@ -136,6 +143,28 @@ void Plan::add_conv(const ConvOp& op) {
   s.lane = cur_lane;
   s.run = [cp](hipStream_t st) { launch_conv(*cp, st); };
   conv_flops += o.flops;
+  conv_launches += 1;
+  steps.push_back(std::move(s));
+}
+
+void Plan::add_trunk(const std::vector<ConvOp>& ops) {
+  Step s;
+  s.is_conv = true;
+  s.trunk = std::make_shared<TrunkPlan>(ops);
+  for (const ConvOp& op : ops) {
+    ConvOp o = op;
+    o.flops = conv_flops_of(*op.pc, op.out.lvl->actual_px());
+    o.force_shape = 25;                                   // nothing to tune: the fused launch has one shape
+    s.fused.push_back(std::make_shared<ConvOp>(o));
+    s.flops += o.flops;
+  }
+  s.conv = s.fused.front();
+  s.variant = "f16_k3s1_trunk";
+  s.name = ops.front().pc->name + ".." + ops.back().pc->name;
+  s.lane = cur_lane;
+  std::shared_ptr<TrunkPlan> tp = s.trunk;
+  s.run = [tp](hipStream_t st) { tp->launch(st); };
+  conv_flops += s.flops;
   conv_launches += 1;
   steps.push_back(std::move(s));
 }
@@ -217,7 +246,7 @@ void Plan::tune(hipStream_t st) {
   static const bool off = [] { const char* e = getenv("FFP_NO_TUNE"); return e && e[0] == '1'; }();
   if (off) return;
   for (Step& s : steps) {
-    if (!s.is_conv || s.conv->force_shape >= 0) continue;
+    if (!s.is_conv || s.trunk || s.conv->force_shape >= 0) continue;
     const int best = conv_tune(*s.conv, st);
     if (best >= 0) {
       s.conv->force_shape = best;
@@ -235,7 +264,7 @@ void Plan::execute(hipStream_t st, ConvProfile* prof) {
       if (s.is_conv) {
         const int slot = prof->open(st);
         s.run(st);
-        prof->close(slot, st, s.variant, conv_flops_of(*s.conv->pc, s.conv->out.lvl->actual_px()), s.name);
+        prof->close(slot, st, s.variant, s.actual_flops(), s.name);
       } else {
         s.run(st);
       }

@@ -5,6 +5,7 @@
 #include "common.hpp"
 #include "det_post.hpp"
 #include "ops.hpp"
+#include "trunk.hpp"
 #include "weights.hpp"
 
 namespace ffp {
@@ -32,6 +33,10 @@ struct Step {
   std::function<void(hipStream_t)> run;
   bool is_conv = false;
   std::shared_ptr<ConvOp> conv;      // is_conv: the descriptor `run` launches (its workgroup shape can be tuned after the plan is laid out)
+  // a fused run of convs (conv_trunk.hip): ONE launch; `fused` lists the layers (FLOP accounting), `conv` is the first of them
+  std::shared_ptr<TrunkPlan> trunk;
+  std::vector<std::shared_ptr<ConvOp>> fused;
+  double actual_flops() const;       // algorithmic FLOPs of the batch the step's level currently describes
   std::string variant, name;
   double flops = 0;
   // lanes: steps of different lanes have no data dependency between a fork and the matching join and may overlap on the device
@@ -80,6 +85,7 @@ struct Plan {
   TView alloc_virtual(Level* l, int C, DType dt);        // a view with a max-|value| slot but no storage yet: a tensor that may be fused away
   void materialize(TView& v);                            // ... and its storage, once some kernel turns out to need it
   void add_conv(const ConvOp& op);
+  void add_trunk(const std::vector<ConvOp>& ops);        // the ops as ONE persistent launch (every op: conv_trunk_layer_ok)
   void add(std::function<void(hipStream_t)> f) { Step s; s.run = std::move(f); s.lane = cur_lane; steps.push_back(std::move(s)); }
   // side lanes (FFP_LANES=0: everything stays on lane 0). New steps go to `cur_lane`.
   int cur_lane = 0;

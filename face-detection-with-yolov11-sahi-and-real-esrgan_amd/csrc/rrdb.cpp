@@ -33,6 +33,24 @@ SrEngine::SrEngine(const void* weights, size_t nbytes, int scale, int num_block,
   const int cin_first = 3 * (scale_ == 2 ? 4 : 1);
   FFP_CHECK(conv("conv_first")->cin_real == cin_first && conv("conv_first")->cout == 64, FFP_ERR_WEIGHTS,
             "conv_first is %d->%d, scale %d expects %d->64", conv("conv_first")->cin_real, conv("conv_first")->cout, scale_, cin_first);
+  fused_body_ = dt_ == F16 && conv_trunk_enabled();
+  for (const auto& kv : convs_) weight_bytes_ += kv.second.w.n + kv.second.w16.n + kv.second.bias.n + kv.second.w_direct.n;
+}
+
+void SrEngine::set_fused_body(bool on) {
+  on = on && dt_ == F16;
+  if (on == fused_body_) return;
+  FFP_HIP(hipSetDevice(device_));
+  if (pending_) wait_done();
+  FFP_HIP(hipStreamSynchronize(st_));
+  plans_.clear();
+  fused_body_ = on;
+}
+
+size_t SrEngine::plan_bytes() const {
+  size_t b = 0;
+  for (const auto& kv : plans_) b += kv.second->bytes;
+  return b;
 }
 
 SrEngine::~SrEngine() {
@@ -74,6 +92,9 @@ void SrEngine::build_plan(SrPlan& P, int cap_t16) {
   TView ring[4];
   for (auto& r : ring) r = P.alloc(P.Lb, 192, T);
 
+  // the body's convs are collected and added as ONE fused step (conv_trunk.hip) when the engine runs the fused body
+  std::vector<ConvOp> body;
+  bool collect = false;
   auto cv = [&](const std::string& name, const TView& in, const TView& out, int act, int up = 0, const TView* r1 = nullptr, float s1 = 1.f,
                 const TView* r2 = nullptr, float s2 = 1.f) {
     ConvOp o;
@@ -82,12 +103,18 @@ void SrEngine::build_plan(SrPlan& P, int cap_t16) {
     if (r2) { o.has_res2 = true; o.res2 = *r2; o.s2 = s2; }
     FFP_CHECK(o.pc->cin == in.C && o.pc->cout == out.C, FFP_ERR_WEIGHTS, "%s: weights are %d->%d, graph expects %d->%d", name.c_str(),
               o.pc->cin, o.pc->cout, in.C, out.C);
-    P.add_conv(o);
+    if (collect) {
+      FFP_CHECK(conv_trunk_layer_ok(o), FFP_ERR_STATE, "%s: not a layer the fused body launch can run", name.c_str());
+      body.push_back(o);
+    } else {
+      P.add_conv(o);
+    }
   };
 
   cv("conv_first", P.input, feat, ACT_NONE);
   cv("conv_first", P.input, ring[0].slice(0, 64), ACT_NONE);   // second copy inside the first dense buffer (3->64: negligible)
   int cur = 0;
+  collect = fused_body_;
   for (int b = 0; b < num_block_; ++b) {
     const TView rrdb_in = ring[cur].slice(0, 64);
     for (int r = 1; r <= 3; ++r) {
@@ -104,6 +131,8 @@ void SrEngine::build_plan(SrPlan& P, int cap_t16) {
     }
     // ring[cur] now holds the RRDB output; the RRDB input slot (3 steps back == (cur+1)&3) is free again
   }
+  collect = false;
+  if (!body.empty()) P.add_trunk(body);
   TView feat2 = P.alloc(P.Lb, 64, T);
   cv("conv_body", ring[cur].slice(0, 64), feat2, ACT_NONE, 0, &feat, 1.0f);            // feat + conv_body(body)
   TView u1 = P.alloc(P.L1, 64, T);

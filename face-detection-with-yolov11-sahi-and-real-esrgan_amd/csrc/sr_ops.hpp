@@ -57,6 +57,13 @@ class SrEngine {
   // caller can overlap the next frame's detection (own stream) with this frame's super-resolution
   void enhance_dev(const uint8_t* d_in, uint8_t* d_out, const std::vector<SrImage>& imgs, int tile, int tile_pad, int pre_pad, bool wait = true);
   void wait_done();
+  // the body (every conv of the residual dense blocks) as ONE persistent launch (conv_trunk.hip) or one launch per layer; bit-identical
+  // results either way. Default: fused in fp16 unless FFP_TRUNK=0. Changing it drops the resident plans.
+  void set_fused_body(bool on);
+  bool fused_body() const { return fused_body_; }
+  size_t plan_bytes() const;    // device memory held by the resident plans (activations, tables), without the packed weights
+  size_t weight_bytes() const { return weight_bytes_; }
+  int plans_resident() const { return (int)plans_.size(); }
 
   DevBuf scratch_in, scratch_out, scratch_boxes, scratch_offs;
   HostPinned crop_stage;
@@ -80,6 +87,8 @@ class SrEngine {
   hipStream_t st_ = nullptr;
   hipEvent_t ev_[2];
   bool pending_ = false;
+  bool fused_body_ = true;
+  size_t weight_bytes_ = 0;
 };
 
 }  // namespace ffp

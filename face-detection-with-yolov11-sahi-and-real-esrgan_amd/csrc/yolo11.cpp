@@ -6,6 +6,7 @@
 #include "yolo11.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace ffp {
 
@@ -57,6 +58,7 @@ DetEngine::DetEngine(const void* weights, size_t nbytes, int arch, int nc, int n
   FFP_CHECK(conv("model.23.cv3.0.2")->cout == nc_ && conv("model.23.cv4.0.2")->cout == 3 * nkpt_, FFP_ERR_WEIGHTS,
             "head shapes (%d classes, %d kpt values) differ from nc=%d nkpt=%d", conv("model.23.cv3.0.2")->cout,
             conv("model.23.cv4.0.2")->cout, nc_, nkpt_);
+  for (const auto& kv : convs_) weight_bytes_ += kv.second.w.n + kv.second.w16.n + kv.second.bias.n + kv.second.w_direct.n + kv.second.oscale.n;
 }
 
 DetEngine::~DetEngine() {
@@ -360,15 +362,37 @@ DetPlan* DetEngine::plan_for(const std::vector<TileGeom>& g) {
   for (const TileGeom& t : g) { key.push_back(t.lb.net_h); key.push_back(t.lb.net_w); }
   auto it = plans_.find(key);
   if (it == plans_.end()) {
-    if (plans_.size() >= 8) plans_.clear();     // bound the cache; plans are cheap to rebuild
+    // bound the cache by count and by bytes: least recently used plans go first (a caller alternating between image_size 512 and 1024, or
+    // between group sizes, keeps what it uses; round 3 dropped everything at the ninth plan and never looked at bytes)
+    static const size_t budget = [] { const char* e = getenv("FFP_DET_PLAN_GIB"); const double g = e ? atof(e) : 64.0; return (size_t)(g * (1ull << 30)); }();
+    auto evict_lru = [&](const DetPlan* keep) {
+      auto victim = plans_.end();
+      for (auto jt = plans_.begin(); jt != plans_.end(); ++jt)
+        if (jt->second.get() != keep && (victim == plans_.end() || jt->second->last_use < victim->second->last_use)) victim = jt;
+      if (victim == plans_.end()) return false;
+      FFP_HIP(hipStreamSynchronize(st_));
+      plans_.erase(victim);
+      return true;
+    };
+    while (plans_.size() >= 8 && evict_lru(nullptr)) {}
     std::unique_ptr<DetPlan> p(new DetPlan());
     p->lanes = lanes_;
     std::vector<int> hs, ws;
     for (const TileGeom& t : g) { hs.push_back(t.lb.net_h); ws.push_back(t.lb.net_w); }
     build_plan(*p, hs, ws);
+    const DetPlan* fresh = p.get();
     it = plans_.emplace(key, std::move(p)).first;
+    while (plan_bytes() > budget && evict_lru(fresh)) {}
+    it = plans_.find(key);
   }
+  it->second->last_use = ++use_clock_;
   return it->second.get();
+}
+
+size_t DetEngine::plan_bytes() const {
+  size_t b = 0;
+  for (const auto& kv : plans_) b += kv.second->bytes;
+  return b;
 }
 
 DetPlan* DetEngine::prepare(const uint8_t* d_frame, int H, int W, int chan_order, const int32_t* tiles, int n_tiles, int imgsz) {

@@ -5,6 +5,7 @@
 namespace ffp {
 
 struct DetPlan : Plan {
+  unsigned long long last_use = 0;
   Level* L[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // strides 1,2,4,8,16,32
   TView input;
   TView head[3];
@@ -37,6 +38,11 @@ class DetEngine {
   hipStream_t stream() const { return st_; }
   int nc() const { return nc_; }
   int nkpt() const { return nkpt_; }
+  // device memory: resident plans (activations + tables; one plan per batch shape, least recently used ones are dropped beyond 8 plans or
+  // beyond the byte budget — env FFP_DET_PLAN_GIB, default 64) and the packed weights
+  size_t plan_bytes() const;
+  size_t weight_bytes() const { return weight_bytes_; }
+  int plans_resident() const { return (int)plans_.size(); }
 
   // crops of a device-resident frame -> per-crop detections (device), crop-local float coords
   void infer_tiles_dev(const uint8_t* d_frame, int H, int W, int chan_order, const int32_t* tiles, int n_tiles, int imgsz,
@@ -72,6 +78,8 @@ class DetEngine {
   std::map<std::vector<int>, std::unique_ptr<DetPlan>> plans_;
   std::vector<TileGeom> geom_last_;
   int lanes_ = 0;
+  unsigned long long use_clock_ = 0;
+  size_t weight_bytes_ = 0;
   int device_ = 0, nc_ = 1, nkpt_ = 5;
   char scale_ = 's';
   DType dt_ = F32;

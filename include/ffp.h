@@ -201,6 +201,16 @@ int ffp_sr_enhance_crops_multi_dev_async(ffp_sr* s, int n_frames, const uint8_t*
  * of crop sizes: out_plans_built counts the layouts built so far (a stream of frames with ever-changing crop sizes must
  * not grow it), out_last_graph tells whether the last call replayed a captured hipGraph (1) or launched eagerly (0). */
 int ffp_sr_plan_state(ffp_sr* s, int32_t* out_plans_built, int32_t* out_last_graph);
+/* The body of RRDBNet (the 345 convs of the residual dense blocks constructed at utils/enhancer.py:121-128) as ONE persistent launch
+ * with per-tile dependency counters (1, the default in fp16) or as one launch per layer (0). Results are bit-identical either way;
+ * the per-layer form is the fused form's parity oracle and A/B partner. Drops the resident plans. */
+int ffp_sr_set_fused_body(ffp_sr* s, int on);
+/* Device memory a handle holds: the packed weights and the resident plans (activations + tables; the detector keeps at most 8 plans
+ * and FFP_DET_PLAN_GIB (default 64) GiB of them, the enhancer at most 4 capacity buckets, least recently used first out). The
+ * reference holds one torch module per model (utils/yolo_wrapper.py:47-61, utils/enhancer.py:156) and lets torch's caching
+ * allocator grow; here a caller that switches image_size or batch shapes can see — and bound — what stays resident. */
+int ffp_sr_mem_bytes(ffp_sr* s, uint64_t* out_weight_bytes, uint64_t* out_plan_bytes, int32_t* out_plans_resident);
+int ffp_det_mem_bytes(ffp_det* d, uint64_t* out_weight_bytes, uint64_t* out_plan_bytes, int32_t* out_plans_resident);
 /* hipGraph state of the plan the detector's last call ran: 1 replayed a captured graph, 0 not captured yet (first runs of a
  * plan are eager), -1 capture failed and the plan keeps launching eagerly (also reported once on stderr). */
 int ffp_det_graph_status(ffp_det* d, int32_t* out_state);
