@@ -75,7 +75,12 @@ VARIANTS = {
     "r16_stash1": (["conv_rows16.hip"], ["-DFFP_R16_STASH=1"]),             # staging placement experiments (tools/rows16_stash_probe.sh)
     "r16_stash2": (["conv_rows16.hip"], ["-DFFP_R16_STASH=2"]),
     "k3d_dbg": (["conv_k3d.hip"], ["-DFFP_K3D_DBG=1"]),
-    "trunk_dbg": (["conv_trunk.hip"], ["-DFFP_TRUNK_DBG=1"]),               # phase-skip / stamp build of the fused-trunk kernel
+    "trunk_dbg": (["conv_trunk.hip"], ["-DFFP_TRUNK_DBG=1"]),               # s_memtime stamps per phase of the fused-body kernel (tools/trunk_stamp_probe.py)
+    "trunk_skip2": (["conv_trunk.hip"], ["-DFFP_TRUNK_SKIP=2"]),            # compile-time phase skips (tools/trunk_phase_probe.py): no MFMA
+    "trunk_skip4": (["conv_trunk.hip"], ["-DFFP_TRUNK_SKIP=4"]),            # no DMA
+    "trunk_skip16": (["conv_trunk.hip"], ["-DFFP_TRUNK_SKIP=16"]),          # no fragment reads
+    "trunk_skip22": (["conv_trunk.hip"], ["-DFFP_TRUNK_SKIP=22"]),          # none of the three
+    "trunk_skip23": (["conv_trunk.hip"], ["-DFFP_TRUNK_SKIP=23"]),          # bare skeleton: control, item set-up, barriers
 }
 
 

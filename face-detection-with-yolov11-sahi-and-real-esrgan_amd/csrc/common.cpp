@@ -66,16 +66,23 @@ void Level::reserve(int cap_n, int64_t cap_px, int cap_tiles16, hipStream_t st) 
 
 // 4th component of a tile entry: the image's tile grid, columns | rows << 16 (conv_trunk.hip finds a tile's neighbours with it)
 static inline int tile_grid(int h, int w, int th) { return ((w + 15) / 16) | (((h + th - 1) / th) << 16); }
+// key < 0: the packed form of tile_table_packed() with tile height -key
+static inline int4 tile_entry(int key, int i, int y, int x, int h, int w, int64_t off) {
+  if (key > 0) return make_int4(i, y, x, tile_grid(h, w, key));
+  return make_int4((int)off, y | (x << 16), h | (w << 16), tile_grid(h, w, -key));
+}
 
 void Level::fill_tiles(int th, TileTab& t, hipStream_t st, size_t* stage_off) {
   // capacity mode: tile rows of the current batch -> staging -> device (only the real entries; kernels bound on d_count)
   int4* dst = reinterpret_cast<int4*>(static_cast<unsigned char*>(stage) + *stage_off);
   int k = 0;
+  const int key = th;
+  th = key < 0 ? -key : key;
   for (int i = 0; i < act_n; ++i)
     for (int y = 0; y < h[i]; y += th)
       for (int x = 0; x < w[i]; x += 16) {
         FFP_CHECK(k < t.cap, FFP_ERR_STATE, "level: batch needs more than %d tiles of height %d", t.cap, th);
-        dst[k++] = make_int4(i, y, x, tile_grid(h[i], w[i], th));
+        dst[k++] = tile_entry(key, i, y, x, h[i], w[i], off[i]);
       }
   dst[k] = make_int4(k, 0, 0, 0);          // the count travels right behind the entries
   t.n = k;
@@ -147,8 +154,15 @@ long long Level::count_tiles(int th) const {
   return t;
 }
 
-const int4* Level::tile_table(int th, int* n_launch, const int** d_count, hipStream_t st) {
-  auto it = tiles.find(th);
+const int4* Level::tile_table_packed(int th, int* n_launch, const int** d_count, hipStream_t st) {
+  for (int i = 0; i < (capacity() ? act_n : n); ++i)
+    FFP_CHECK(h[i] < 65536 && w[i] < 65536 && off[i] < (1ll << 31), FFP_ERR_ARG, "level: image %d (%dx%d) is too large for packed tile entries", i, w[i], h[i]);
+  return tile_table(-th, n_launch, d_count, st);
+}
+
+const int4* Level::tile_table(int key, int* n_launch, const int** d_count, hipStream_t st) {
+  const int th = key < 0 ? -key : key;
+  auto it = tiles.find(key);
   if (it == tiles.end()) {
     TileTab t;
     if (capacity()) {
@@ -159,7 +173,7 @@ const int4* Level::tile_table(int th, int* n_launch, const int** d_count, hipStr
       std::vector<int4> v;
       for (int i = 0; i < act_n; ++i)
         for (int y = 0; y < h[i]; y += th)
-          for (int x = 0; x < w[i]; x += 16) v.push_back(make_int4(i, y, x, tile_grid(h[i], w[i], th)));
+          for (int x = 0; x < w[i]; x += 16) v.push_back(tile_entry(key, i, y, x, h[i], w[i], off[i]));
       FFP_CHECK((int)v.size() <= t.cap, FFP_ERR_STATE, "level: batch needs more than %d tiles of height %d", t.cap, th);
       t.n = (int)v.size();
       if (t.n > 0) FFP_HIP(hipMemcpyAsync(t.tab.p, v.data(), sizeof(int4) * v.size(), hipMemcpyHostToDevice, st));
@@ -169,13 +183,13 @@ const int4* Level::tile_table(int th, int* n_launch, const int** d_count, hipStr
       std::vector<int4> v;
       for (int i = 0; i < n; ++i)
         for (int y = 0; y < h[i]; y += th)
-          for (int x = 0; x < w[i]; x += 16) v.push_back(make_int4(i, y, x, tile_grid(h[i], w[i], th)));
+          for (int x = 0; x < w[i]; x += 16) v.push_back(tile_entry(key, i, y, x, h[i], w[i], off[i]));
       t.tab.alloc(sizeof(int4) * v.size());
       FFP_HIP(hipMemcpyAsync(t.tab.p, v.data(), sizeof(int4) * v.size(), hipMemcpyHostToDevice, st));
       FFP_HIP(hipStreamSynchronize(st));
       t.n = (int)v.size();
     }
-    it = tiles.emplace(th, std::move(t)).first;
+    it = tiles.emplace(key, std::move(t)).first;
   }
   const TileTab& t = it->second;
   *n_launch = capacity() ? t.cap : t.n;

@@ -134,6 +134,9 @@ struct Level {
   int actual_n() const { return capacity() ? act_n : n; }
   // *n_launch: tiles to launch (capacity mode: the table capacity); *d_count: device count of real tiles (capacity mode) or nullptr
   const int4* tile_table(int th, int* n_launch, const int** d_count, hipStream_t st);
+  // the same tiles in the PACKED form of conv_trunk.hip, everything a work item needs in one 16-byte load:
+  //   {first pixel of the image, y0 | x0 << 16, h | w << 16, tile columns | tile rows << 16 of the image}   (kept under key -th)
+  const int4* tile_table_packed(int th, int* n_launch, const int** d_count, hipStream_t st);
   // for every pixel of this level the flat pixel index of its nearest-x2 source in `src` (same images at half size)
   std::map<const Level*, DevBuf> up2_maps;
   const int* up2_map(const Level* src, hipStream_t st);

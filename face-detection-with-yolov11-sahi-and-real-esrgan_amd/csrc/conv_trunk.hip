@@ -32,7 +32,10 @@
 #include "trunk.hpp"
 
 #ifndef FFP_TRUNK_DBG
-#define FFP_TRUNK_DBG 0        // 1: diagnostic build (phase-skip bits in TrunkArgs::dbg: 1 epilogue, 2 MFMA, 4 DMA, 16 fragment reads)
+#define FFP_TRUNK_DBG 0        // 1: diagnostic build — s_memtime stamps per phase of every iteration, sums of workgroup 0 behind the queue words (FFP_TRUNK_DUMP=1 prints them)
+#endif
+#ifndef FFP_TRUNK_SKIP
+#define FFP_TRUNK_SKIP 0       // diagnostic builds: COMPILE-TIME phase-skip bits (what is left keeps the production schedule): 1 epilogue, 2 MFMA, 4 DMA, 16 fragment reads
 #endif
 
 namespace ffp {
@@ -55,7 +58,8 @@ struct TG {
 };
 
 enum : int { D_EMPTY = 0, D_KNOWN = 1, D_READY = 2, D_END = 3 };
-// descriptor slot (16 ints in LDS): 0 state, 1 queue id, 2 layer, 3 tile index, 4 image, 5 y0, 6 x0, 7 tiles_x | tiles_y << 16
+// descriptor slot (16 ints in LDS): 0 state, 1 queue id, 2 layer, 3 tile index, 4 first pixel of the image, 5 y0 | x0 << 16, 6 h | w << 16,
+// 7 tile columns | tile rows << 16 of the image (4..7 = the packed tile entry, Level::tile_table_packed)
 
 __device__ __forceinline__ unsigned rfl(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -85,10 +89,10 @@ template <bool SC1> __device__ __forceinline__ void dma16(u32x4 rs, unsigned vof
 }
 
 struct Item {            // wave-uniform description of a work item (SGPRs)
-  int layer, tile, img, y0, x0;
+  int layer, tile, y0, x0;
   int NC, NT;            // 32-channel input chunks, 32-channel output blocks (1 or 2)
   int H, W;              // image size
-  long long px0;         // first pixel of the image in the level
+  int px0;               // first pixel of the image in the level
 };
 
 template <bool COH>      // COH: several layers in one launch — sc1 loads / stores of activations and the done[] protocol
@@ -110,17 +114,6 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
   constexpr unsigned OOB = 0xFFFFFFFFu;
   constexpr int AUXC = COH ? 16 : 0;                          // sc1 on activation loads / stores of a multi-layer launch
 
-  // ---- per-lane constants of the staging: pixel pieces wave + 8 i (i < 5; piece < 39), lane -> halo pixel q = piece * 16 + lane / 4 and
-  // LDS slot position lane % 4, which holds SOURCE slot (lane % 4) ^ ((hx >> 1) & 2): the fragment reads below are then conflict free
-  unsigned hyx[5];         // (source slot << 16) | (hy << 8) | hx, or 0xFFFFFFFF for a dummy pixel / a piece this wave does not have
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int p = wave + 8 * i;
-    const int q = p * 16 + (lane >> 2);
-    const int hy = q / G::HC, hx = q - hy * G::HC;
-    const int s = (lane & 3) ^ ((hx >> 1) & 2);
-    hyx[i] = (p < G::PIX_PIECES && q < G::HR * G::HC) ? (unsigned)((s << 16) | (hy << 8) | hx) : OOB;
-  }
   unsigned isrc[5];        // byte offset of the lane's 16 bytes of chunk 0 from the image's first pixel record (+ in_coff), or OOB
 
   // fragment read offsets: halo rows 4 * wave + j (j = 0..5), column pc + kx, slot g
@@ -134,98 +127,117 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
 
   // ---- control (wave 0): the queue, the tile entries and the dependency counters of the next three items, one step per chunk -------------
   int ck = -1;             // sequence number (within this workgroup) of the CURRENT item (-1: none yet); slot = seq & 3
-  int fk = 0, fstate = 0;  // fetcher: next sequence number to fetch; 0 idle, 1 queue id pending, 2 tile entry pending, 3 queue exhausted
+  int fk = 0, fstate = 0;  // fetcher: next sequence number to fetch; 0 idle, 1 queue id asked, 2 id known, 3 tile entry asked, 4 queue exhausted
   int f_id = 0;            // pending atomic result (lane 0)
   u32x4 f_tile = {0u, 0u, 0u, 0u};
   int f_layer = 0, f_t = 0;
   unsigned f_qid = 0;
+  // wave 0's own copy of the four descriptor slots (scalar registers; LDS holds what the other waves read): state, layer, tile index,
+  // tile position and grid packed as tx | ty << 8 | nx << 16 | ny << 24 — a control step reads no LDS
+  int s_st[4] = {0, 0, 0, 0}, s_ly[4] = {0, 0, 0, 0}, s_tt[4] = {0, 0, 0, 0}, s_geo[4] = {0, 0, 0, 0};
+  auto get4 = [](const int (&v)[4], int k) { return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : v[3]; };
+  auto put4 = [](int (&v)[4], int k, int x) { v[0] = k == 0 ? x : v[0]; v[1] = k == 1 ? x : v[1]; v[2] = k == 2 ? x : v[2]; v[3] = k == 3 ? x : v[3]; };
   int p_base = -1;         // polls in flight: sequence number of lane group 0 (-1: none)
   unsigned p_val = 0;
-  // Every memory operation of a control step is issued UNCONDITIONALLY — through buffer descriptors, with an out-of-range offset where the
-  // step has nothing to ask (the range check drops the request) — and consumed one step later: behind an exec-masked or conditional
-  // load hipcc waits for vmcnt(0) at once, which would park wave 0 for a memory round trip (an atomic: 1-2 us) in front of its MFMAs.
+  int p_need = 0;          // per lane: the layer its polled counter must have reached
+  bool p_act = false;      // per lane: it polled a counter
   const auto rs_sync = __builtin_amdgcn_make_buffer_rsrc(a.queue, 0, 64 + 4 * n_tiles, 0x00020000);          // [queue | done[]]
   const auto rs_tiles = __builtin_amdgcn_make_buffer_rsrc(const_cast<int4*>(a.tiles), 0, 16 * n_tiles, 0x00020000);
   // "nothing to ask" offset of the control step's dword / atomic operations: aligned and beyond any num_records (0xFFFFFFFF + 4 wraps in
   // a 32-bit range check; a buffer ATOMIC at that offset faulted with a memory aperture violation on gfx950, 16-byte loads do not)
   constexpr unsigned OOBA = 0x80000000u;
-  auto control_step = [&]() {
-    // 1. consume the fetch issued one step ago
-    unsigned tile_off = OOBA;
+  // A control step has two halves. control_issue() — at the top of an iteration — asks: the queue for the next id (at most three items ahead),
+  // or the tile table for the id it got, and (multi-layer launches) the dependency counters of every fetched, not yet ready item.
+  // control_consume() — at the END of the iteration, right after the wave's full vmcnt(0) wait — reads the answers. Every request is a buffer
+  // operation issued unconditionally inside the step (an out-of-range offset where there is nothing to ask): behind exec-masked loads, or for
+  // results carried over the loop's back edge, hipcc waits for vmcnt(0) at the point of use, and that wait would also cover the epilogue's
+  // stores (1-2 us: measured 1,500 cycles per iteration with the one-step form). A last-chunk iteration (stores still in flight at its end)
+  // skips the consume; nothing new is asked until the answers have been read.
+  unsigned f_tile_off = OOBA;
+  bool ctl_pending = false;
+  auto control_issue = [&]() {
+    if (ctl_pending) return;
+    const bool want_id = fstate == 0 && fk <= ck + 3;
+    const bool want_tile = fstate == 2;
+    const bool want_poll = COH && (s_st[0] == D_KNOWN || s_st[1] == D_KNOWN || s_st[2] == D_KNOWN || s_st[3] == D_KNOWN);
+    if (!want_id && !want_tile && !want_poll) return;          // the steady state of a large batch: three items fetched and ready
+    f_id = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rs_sync, (want_id && lane == 0) ? 0u : OOBA, 0, 0);
+    f_tile = __builtin_amdgcn_raw_buffer_load_b128(rs_tiles, want_tile ? f_tile_off : OOBA, 0, 0);
+    if (want_id) fstate = 1;
+    if (want_tile) fstate = 3;
+    if (COH) {              // tile t and its neighbours t + dy * nx + dx inside the image's tile grid: lane group gi asks for sequence ck + 1 + gi
+      const int gi = lane >> 4, j = lane & 15;
+      const int sq = ck + 1 + gi, k = sq & 3;
+      const int stt = get4(s_st, k), geo = get4(s_geo, k), t = get4(s_tt, k);
+      p_need = get4(s_ly, k);
+      p_act = gi < 3 && j < 9 && sq < fk && stt == D_KNOWN;
+      const int dy = j / 3 - 1, dx = j - (j / 3) * 3 - 1;
+      const int tx = geo & 0xFF, ty = (geo >> 8) & 0xFF, nx = (geo >> 16) & 0xFF, ny = (geo >> 24) & 0xFF;
+      const bool in = (unsigned)(tx + dx) < (unsigned)nx && (unsigned)(ty + dy) < (unsigned)ny;
+      const unsigned off = p_act ? 64u + 4u * (unsigned)(in ? t + dy * nx + dx : t) : OOBA;
+      p_val = __builtin_amdgcn_raw_buffer_load_b32(rs_sync, off, 0, 16);      // sc1: the counters are written by other workgroups
+      p_base = __builtin_amdgcn_ballot_w64(p_act) != 0 ? ck + 1 : -1;
+    }
+    ctl_pending = true;
+  };
+  auto control_consume = [&]() {
+    if (!ctl_pending) return;
+    ctl_pending = false;
     if (fstate == 1) {
       const unsigned id = (unsigned)rfl(f_id);
       if (id >= total) {
+        put4(s_st, fk & 3, D_END);
         if (lane == 0) desc[(fk & 3) * 16] = D_END;
-        fstate = 3;
+        fstate = 4;
       } else {
         f_qid = id;
         f_layer = (int)(id / (unsigned)n_tiles);
         f_t = (int)(id - (unsigned)f_layer * (unsigned)n_tiles);
-        tile_off = (unsigned)f_t * 16u;
+        f_tile_off = (unsigned)f_t * 16u;
         fstate = 2;
       }
-    } else if (fstate == 2) {
-      const int img = rfl((int)f_tile[0]), y0 = rfl((int)f_tile[1]), x0 = rfl((int)f_tile[2]), txy = rfl((int)f_tile[3]);
+    } else if (fstate == 3) {
+      const int e0 = rfl((int)f_tile[0]), e1 = rfl((int)f_tile[1]), e2 = rfl((int)f_tile[2]), txy = rfl((int)f_tile[3]);
+      const int k = fk & 3;
+      const int state = (COH && f_layer > 0) ? D_KNOWN : D_READY;       // the first layer of a launch depends on earlier launches only
+      put4(s_st, k, state); put4(s_ly, k, f_layer); put4(s_tt, k, f_t);
+      put4(s_geo, k, ((e1 >> 16) >> 4) | (((e1 & 0xFFFF) / G::TH) << 8) | ((txy & 0xFF) << 16) | (((txy >> 16) & 0xFF) << 24));
       if (lane == 0) {
-        int* d = desc + (fk & 3) * 16;
-        d[1] = (int)f_qid; d[2] = f_layer; d[3] = f_t; d[4] = img; d[5] = y0; d[6] = x0; d[7] = txy;
-        d[0] = (COH && f_layer > 0) ? D_KNOWN : D_READY;       // the first layer of a launch depends on earlier launches only
+        int* d = desc + k * 16;
+        d[1] = (int)f_qid; d[2] = f_layer; d[3] = f_t; d[4] = e0; d[5] = e1; d[6] = e2; d[7] = txy;
+        d[0] = state;
       }
       ++fk;
       fstate = 0;
     }
-    // 2. consume the polls issued one step ago: group gi (lanes 16 gi .. 16 gi + 8) -> sequence p_base + gi
     if (COH && p_base >= 0) {
+      const unsigned long long okm = __builtin_amdgcn_ballot_w64(!p_act || (int)p_val >= p_need);
+      const unsigned long long actm = __builtin_amdgcn_ballot_w64(p_act);
 #pragma unroll
       for (int gi = 0; gi < 3; ++gi) {
-        const int sq = p_base + gi;
-        int* d = desc + (sq & 3) * 16;
-        if (sq > ck && sq < fk && d[0] == D_KNOWN) {
-          const int need = d[2];
-          const bool mine = (lane >> 4) == gi && (lane & 15) < 9;
-          const bool ok = !mine || (int)p_val >= need;
-          if (__builtin_amdgcn_ballot_w64(ok) == ~0ull && lane == 0) d[0] = D_READY;
+        const unsigned long long gm = 0x1FFull << (16 * gi);
+        if ((actm & gm) != 0 && (okm & gm) == gm) {
+          const int k = (p_base + gi) & 3;
+          put4(s_st, k, D_READY);
+          if (lane == 0) desc[k * 16] = D_READY;
         }
       }
       p_base = -1;
     }
-    // 3. the next fetch step: ids are taken at most three items ahead of the current one
-    bool take = false;
-    if (fstate == 0 && fk <= ck + 3) { take = true; fstate = 1; }
-    f_id = __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rs_sync, (take && lane == 0) ? 0u : OOBA, 0, 0);
-    f_tile = __builtin_amdgcn_raw_buffer_load_b128(rs_tiles, tile_off, 0, 0);
-    // 4. poll the counters of every fetched, not yet ready item: tile t and its neighbours t + dy * tiles_x + dx inside the image
-    if (COH) {
-      bool any = false;
-      unsigned off = OOBA;
-#pragma unroll
-      for (int gi = 0; gi < 3; ++gi) {
-        const int sq = ck + 1 + gi;
-        const int* d = desc + (sq & 3) * 16;
-        if (sq < fk && d[0] == D_KNOWN) {
-          any = true;
-          const int j = lane & 15, dy = j / 3 - 1, dx = j - (j / 3) * 3 - 1;
-          const int t = d[3], tx = d[6] >> 4, ty = d[5] / G::TH, nx = d[7] & 0xFFFF, ny = d[7] >> 16;
-          const bool in = (unsigned)(tx + dx) < (unsigned)nx && (unsigned)(ty + dy) < (unsigned)ny;
-          if ((lane >> 4) == gi && j < 9) off = 64u + 4u * (unsigned)(in ? t + dy * nx + dx : t);
-        }
-      }
-      p_val = __builtin_amdgcn_raw_buffer_load_b32(rs_sync, off, 0, 16);      // sc1: the counters are written by other workgroups
-      if (any) p_base = ck + 1;
-    }
   };
-  // blocking form (prologue, late dependencies): until the item after `ck_prev` is READY or the queue has ended. Bounded: a spin that
-  // never ends would hang the device — it gives up, raises the error word and ends this workgroup's walk instead
+  // blocking form (prologue, late dependencies): until sequence `sq` is READY or the queue has ended. Bounded: a spin that never ends
+  // would hang the device — it gives up, raises the error word and ends this workgroup's walk instead
   auto control_wait = [&](int sq) {
-    int* d = desc + (sq & 3) * 16;
     for (int spin = 0;; ++spin) {
-      const int s = d[0];
-      if (s == D_READY || s == D_END) break;
+      const int st = get4(s_st, sq & 3);
+      if (st == D_READY || st == D_END) break;
       if (spin > (1 << 22)) {
-        if (lane == 0) { atomicAdd(a.queue + 1, 1u); d[0] = D_END; }
+        if (lane == 0) { atomicAdd(a.queue + 1, 1u); desc[(sq & 3) * 16] = D_END; }
+        put4(s_st, sq & 3, D_END);
         break;
       }
-      control_step();
+      control_issue();
+      control_consume();
       if (spin > 4) __builtin_amdgcn_s_sleep(4);
     }
   };
@@ -235,49 +247,61 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
 
   // ---- item set-up: descriptor slot -> SGPRs, per-lane source offsets of the halo pixels ------------------------------------------------
   auto load_item = [&](int sq) {
-    const int* d = desc + (sq & 3) * 16;
+    const int4 d0 = *reinterpret_cast<const int4*>(desc + (sq & 3) * 16), d1 = *reinterpret_cast<const int4*>(desc + (sq & 3) * 16 + 4);
     Item it;
-    it.layer = rfl(d[2]); it.tile = rfl(d[3]); it.img = rfl(d[4]); it.y0 = rfl(d[5]); it.x0 = rfl(d[6]);
-    const int4 im = a.img_tab[it.img];
-    it.px0 = rfl(im.x); it.H = rfl(im.y); it.W = rfl(im.z);
+    it.layer = rfl(d0.z); it.tile = rfl(d0.w);
+    it.px0 = rfl(d1.x);
+    const int yx = rfl(d1.y), hw = rfl(d1.z);
+    it.y0 = yx & 0xFFFF; it.x0 = (int)((unsigned)yx >> 16);
+    it.H = hw & 0xFFFF; it.W = (int)((unsigned)hw >> 16);
     it.NC = layers[it.layer].cin >> 5;
     it.NT = layers[it.layer].cout >> 5;
     return it;
   };
-  u32x4 rs_in, rs_w;
+  u32x4 rs_in, rs_w, rs_b;
   auto setup_dma = [&](const Item& it) {
     const LPtr L = layers + it.layer;
     const int cs = L->in_cs;
-    const unsigned char* inb = reinterpret_cast<const unsigned char*>(L->in) + (it.px0 * cs + L->in_coff) * 2;
+    const unsigned char* inb = reinterpret_cast<const unsigned char*>(L->in) + ((long long)it.px0 * cs + L->in_coff) * 2;
     rs_in = make_rsrc(inb, 0x7FFFFFF0u);
     rs_w = make_rsrc(L->wpk, (unsigned)(it.NT * it.NC * G::WB));
+    rs_b = make_rsrc(L->bias, (unsigned)(it.NT * 128));
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int hy = (int)(hyx[i] >> 8) & 0xFF, hx = (int)hyx[i] & 0xFF, sl = (int)(hyx[i] >> 16) & 3;
+    for (int i = 0; i < 5; ++i) {                    // pixel piece wave + 8 i: lane -> halo pixel q = piece * 16 + lane / 4, LDS slot position lane % 4
+      const int p = wave + 8 * i;
+      const int q = p * 16 + (lane >> 2);
+      const int hy = (q * 3641) >> 16, hx = q - hy * G::HC;          // q / 18 for q < 640
+      const int sl = (lane & 3) ^ ((hx >> 1) & 2);                   // which holds SOURCE slot (lane % 4) ^ ((hx >> 1) & 2): conflict-free fragment reads
       const int iy = it.y0 - 1 + hy, ix = it.x0 - 1 + hx;
-      const bool ok = hyx[i] != OOB && (unsigned)iy < (unsigned)it.H && (unsigned)ix < (unsigned)it.W;
+      const bool ok = p < G::PIX_PIECES && q < G::HR * G::HC && (unsigned)iy < (unsigned)it.H && (unsigned)ix < (unsigned)it.W;
       isrc[i] = ok ? (unsigned)((iy * it.W + ix) * cs * 2 + sl * 16) : OOB;
     }
   };
-  // chunk c of the item -> stage at LDS byte address `st`: <= 5 pixel pieces + <= 3 (5) weight pieces per wave; the chunk's 64 bytes
-  // per pixel ride in the instruction's scalar offset (not part of the range check: OOB lanes stay out of range)
-  auto issue_dma = [&](const Item& it, int c, unsigned st) {
-    if (FFP_TRUNK_DBG && (a.dbg & 4)) return;
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-      if (wave + 8 * i < G::PIX_PIECES) dma16<COH>(rs_in, isrc[i], (unsigned)(c * 64), st + (unsigned)((wave + 8 * i) << 10));
-    const int nwp = it.NT * 18;
-    for (int q = wave; q < nwp; q += 8) {
-      const int nt = q >= 18 ? 1 : 0, pq = q - nt * 18;
-      dma16<false>(rs_w, (unsigned)lane * 16u, (unsigned)(((nt * it.NC + c) * 18 + pq) << 10), st + (unsigned)(G::PIX + (q << 10)));
+  // chunk c of the item -> stage at LDS byte address `st`: <= 5 pixel pieces + <= 3 (5) weight pieces per wave, issued as ten STEPS (one per
+  // MFMA step of the chunk being multiplied, so that the instructions' issue time — 60-185 cycles each while the address unit is busy —
+  // sits in the matrix instructions' shadow instead of in front of them). The chunk's 64 bytes per pixel ride in the scalar offset.
+  auto dma_piece = [&](const Item& it, int c, unsigned st, int step) {
+    if ((FFP_TRUNK_SKIP & 4)) return;
+    if (step < 5) {
+      if (wave + 8 * step < G::PIX_PIECES) dma16<COH>(rs_in, isrc[step], (unsigned)(c * 64), st + (unsigned)((wave + 8 * step) << 10));
+      else if (c == 0) dma16<false>(rs_b, (unsigned)lane * 16u, 0u, st + (unsigned)(G::PIX_PIECES << 10));   // the layer's bias: piece 39 of chunk 0's stage (wave 7)
+    } else {
+      const int q = wave + 8 * (step - 5);
+      if (q < it.NT * 18) {
+        const int nt = q >= 18 ? 1 : 0, pq = q - nt * 18;
+        dma16<false>(rs_w, (unsigned)lane * 16u, (unsigned)(((nt * it.NC + c) * 18 + pq) << 10), st + (unsigned)(G::PIX + (q << 10)));
+      }
     }
+  };
+  auto issue_dma = [&](const Item& it, int c, unsigned st) {
+#pragma unroll
+    for (int step = 0; step < 10; ++step) dma_piece(it, c, st, step);
   };
 
   // ---- arithmetic: conv_rows16_kernel's chunk, for NM = 2 NT M-tiles -----------------------------------------------------------------------
   f32x4 acc[4][4];
-  auto init_acc = [&](const Item& it) {
-    const LPtr L = layers + it.layer;
-    const float* b = L->bias;
+  auto init_acc = [&](const Item& it, const unsigned char* sb) {      // the bias came with chunk 0's stage (piece 39): no global load at an item's start
+    const float* b = reinterpret_cast<const float*>(sb + (G::PIX_PIECES << 10));
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       if (nt < it.NT) {
@@ -291,34 +315,51 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
       }
     }
   };
-  auto chunk = [&](const unsigned char* sb, auto nm_tag) {
+  auto chunk = [&](const unsigned char* sb, auto nm_tag, auto&& between) {
     constexpr int NM = decltype(nm_tag)::value;
-    uint4 bq[2][6], aq[3][NM];
-    auto ldB = [&](int kx, int q) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) bq[q][j] = *reinterpret_cast<const uint4*>(sb + boff[kx] + j * G::ROWB);
+    // Input-row fragments in EIGHT rolling slots instead of two sets of six: fragment (kx, row r) lives in slot (r + 6 kx) % 8 and is read
+    // from LDS at least one step before its first MFMA, into a slot whose previous row is dead (row r of a kx serves the steps ky = r - 3 .. r):
+    //   step 0: (1,0) (1,1) | 1: (1,2) | 2: (1,3) | 3: (1,4) (1,5) | 4: (2,0) (2,1) (2,2) | 5: (2,3) | 6: (2,4) (2,5)
+    // 16 registers fewer than the double set; the weight fragments are one step ahead (a step is 8 or 16 MFMAs: 128 / 256 cycles of cover).
+    uint4 bq[8] = {}, aq[2][NM] = {};
+    auto ldB1 = [&](int kx, int r) {
+      if ((FFP_TRUNK_SKIP & 16)) { asm volatile("" : "+v"(bq[(r + 6 * kx) & 7].x), "+v"(bq[(r + 6 * kx) & 7].y), "+v"(bq[(r + 6 * kx) & 7].z), "+v"(bq[(r + 6 * kx) & 7].w)); return; }
+      bq[(r + 6 * kx) & 7] = *reinterpret_cast<const uint4*>(sb + boff[kx] + r * G::ROWB);
     };
     auto ldA = [&](int s, int q) {
       const int tap = (s % 3) * 3 + s / 3;
+      if ((FFP_TRUNK_SKIP & 16)) {
+#pragma unroll
+        for (int mm = 0; mm < NM; ++mm) asm volatile("" : "+v"(aq[q][mm].x), "+v"(aq[q][mm].y), "+v"(aq[q][mm].z), "+v"(aq[q][mm].w));
+        return;
+      }
 #pragma unroll
       for (int mm = 0; mm < NM; ++mm) aq[q][mm] = *reinterpret_cast<const uint4*>(sb + aoff + (((mm >> 1) * 18 + tap * 2 + (mm & 1)) << 10));
     };
-    ldB(0, 0);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) ldB1(0, r);
     ldA(0, 0);
-    ldA(1, 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
       const int kx = s / 3, ky = s - 3 * kx;
-      if (s + 2 < 9) ldA(s + 2, (s + 2) % 3);
-      if (ky == 0 && kx < 2) ldB(kx + 1, (kx + 1) & 1);
+      if (s + 1 < 9) ldA(s + 1, (s + 1) & 1);
+      if (s == 0) { ldB1(1, 0); ldB1(1, 1); }
+      if (s == 1) ldB1(1, 2);
+      if (s == 2) ldB1(1, 3);
+      if (s == 3) { ldB1(1, 4); ldB1(1, 5); }
+      if (s == 4) { ldB1(2, 0); ldB1(2, 1); ldB1(2, 2); }
+      if (s == 5) ldB1(2, 3);
+      if (s == 6) { ldB1(2, 4); ldB1(2, 5); }
+      between(s);
+      if (s == 8) between(9);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int mm = 0; mm < NM; ++mm) {
-          if (FFP_TRUNK_DBG && (a.dbg & 2)) continue;
+          if ((FFP_TRUNK_SKIP & 2)) continue;
           union { uint4 u; f16x8 h; } ua, ub;
-          ua.u = aq[s % 3][mm]; ub.u = bq[kx & 1][i + ky];
+          ua.u = aq[s & 1][mm]; ub.u = bq[(i + ky + 6 * kx) & 7];
           acc[i][mm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ua.h, ub.h, acc[i][mm], 0, 0, 0);
         }
 #pragma unroll
@@ -331,21 +372,34 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
   };
 
   // ---- epilogue: lane (pc, g) holds channels 32 nt + 8 g .. + 7 of pixel (row 4 * wave + i, column pc); 4 NT stores per wave -----------------
-  auto epilogue = [&](const Item& it) {
+  struct Epi {             // the epilogue's layer parameters (scalar loads issued BEFORE the last chunk's MFMAs: their latency is off the item's tail)
+    const unsigned char *ob, *r1b, *r2b;
+    int act, o_cs, r1_cs, r2_cs;
+    float s1, s2;
+    bool has1, has2;
+  };
+  auto load_epi = [&](const Item& it) {
     const LPtr L = layers + it.layer;
-    const int act = L->act;
-    const float s1 = L->s1, s2 = L->s2;
-    const int o_cs = L->out_cs, r1_cs = L->r1_cs, r2_cs = L->r2_cs;
-    const bool has1 = L->res1 != nullptr, has2 = L->res2 != nullptr;
-    unsigned char* ob = reinterpret_cast<unsigned char*>(L->out) + (it.px0 * o_cs + L->out_coff) * 2;
-    const unsigned char* r1b = has1 ? reinterpret_cast<const unsigned char*>(L->res1) + (it.px0 * r1_cs + L->r1_coff) * 2 : ob;
-    const unsigned char* r2b = has2 ? reinterpret_cast<const unsigned char*>(L->res2) + (it.px0 * r2_cs + L->r2_coff) * 2 : ob;
+    Epi e;
+    e.act = L->act; e.s1 = L->s1; e.s2 = L->s2;
+    e.o_cs = L->out_cs; e.r1_cs = L->r1_cs; e.r2_cs = L->r2_cs;
+    e.has1 = L->res1 != nullptr; e.has2 = L->res2 != nullptr;
+    e.ob = reinterpret_cast<const unsigned char*>(L->out) + ((long long)it.px0 * e.o_cs + L->out_coff) * 2;
+    e.r1b = e.has1 ? reinterpret_cast<const unsigned char*>(L->res1) + ((long long)it.px0 * e.r1_cs + L->r1_coff) * 2 : e.ob;
+    e.r2b = e.has2 ? reinterpret_cast<const unsigned char*>(L->res2) + ((long long)it.px0 * e.r2_cs + L->r2_coff) * 2 : e.ob;
+    return e;
+  };
+  auto epilogue = [&](const Item& it, const Epi& e) {
+    const int act = e.act;
+    const float s1 = e.s1, s2 = e.s2;
+    const int o_cs = e.o_cs, r1_cs = e.r1_cs, r2_cs = e.r2_cs;
+    const bool has1 = e.has1, has2 = e.has2;
     auto mk = [](const unsigned char* q) {
       const unsigned long long u = reinterpret_cast<unsigned long long>(q);
       const unsigned lo = rfl((unsigned)u), hi = rfl((unsigned)(u >> 32));
       return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(((unsigned long long)hi << 32) | lo), 0, 0x7FFFFFF0, 0x00020000);
     };
-    const auto rs_o = mk(ob), rs_r1 = mk(r1b), rs_r2 = mk(r2b);
+    const auto rs_o = mk(e.ob), rs_r1 = mk(e.r1b), rs_r2 = mk(e.r2b);
     const int ox = it.x0 + pc;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -387,7 +441,7 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
     }
   };
   auto publish = [&](int tile, int layer) {        // every wave has drained its stores and the workgroup has met at a barrier since
-    if (FFP_TRUNK_DBG && (a.dbg & 64)) return;
+    if ((FFP_TRUNK_SKIP & 64)) return;
     if (COH && tid == 0) __hip_atomic_store(a.done + tile, (unsigned)(layer + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto wait_all = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
@@ -398,63 +452,84 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
   if (rfl(desc[0]) != D_READY) return;
   ck = 0;
   Item cur = load_item(0);
-  if (FFP_TRUNK_DBG && (a.dbg & 512)) {              // diagnostic: what the first item of workgroup 0 looks like, then every workgroup ends
-    if (blockIdx.x == 0 && tid == 0) {
-      a.queue[2] = (unsigned)cur.layer; a.queue[3] = (unsigned)cur.tile; a.queue[4] = (unsigned)cur.img; a.queue[5] = (unsigned)cur.y0; a.queue[6] = (unsigned)cur.x0;
-      a.queue[7] = (unsigned)cur.NC; a.queue[8] = (unsigned)cur.NT; a.queue[9] = (unsigned)cur.H; a.queue[10] = (unsigned)cur.W; a.queue[11] = (unsigned)cur.px0;
-      a.queue[12] = (unsigned)n_tiles; a.queue[13] = total; a.queue[14] = (unsigned)desc[7];
-    }
-    return;
-  }
   setup_dma(cur);
   issue_dma(cur, 0, lds0);
-  init_acc(cur);
-  if (FFP_TRUNK_DBG && (a.dbg & 1024)) return;
   wait_all();
   __syncthreads();
+  init_acc(cur, smem);
   int c = 0;
   unsigned stage = 0;
   int pub_tile = -1, pub_layer = 0;
   // One iteration = one chunk. Whether the NEXT item can be prefetched is decided from a snapshot that wave 0 wrote during the PREVIOUS
   // iteration (snap[parity]): every wave of the workgroup takes the same branch, whatever wave 0's control step is doing meanwhile.
+#if FFP_TRUNK_DBG
+  unsigned long long tsum[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();      // control, next-item set-up, chunk, epilogue, wait, barrier, slow path
+  unsigned n_iter = 0, n_slow = 0;
+#define TSTAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsum[k] += t_ - tprev; tprev = t_; }
+#define TDUMP() if (blockIdx.x == 0 && lane == 0 && wave < 2) { unsigned* o = a.queue + 2 + wave * 7; for (int k_ = 0; k_ < 7; ++k_) o[k_] = (unsigned)(tsum[k_] / (n_iter ? n_iter : 1)); \
+                  if (wave == 0) { a.queue[1] = 0; } if (wave == 1) { o[6] = n_iter | (n_slow << 16); } }
+#else
+#define TSTAMP(k)
+#define TDUMP()
+#endif
+  bool have_nxt = false;
+  Item nxt = cur;
   for (unsigned itn = 0;; ++itn) {
     const bool last = c == cur.NC - 1;
-    const bool pre = last && rfl(snap[itn & 1u]) != 0;
-    if (wave == 0) {
-      control_step();
-      const int nseq = pre ? ck + 2 : ck + 1;                    // the item that will be "next" in the following iteration
-      if (lane == 0) snap[(itn + 1u) & 1u] = desc[(nseq & 3) * 16] == D_READY ? 1 : 0;
-    }
-    Item nxt = cur;
-    if (!last) {
-      issue_dma(cur, c + 1, lds0 + (stage ^ 1u) * G::STAGE);
-    } else if (pre) {
-      nxt = load_item(ck + 1);
-      setup_dma(nxt);
-      issue_dma(nxt, 0, lds0 + (stage ^ 1u) * G::STAGE);
-    }
+    const bool pre = last && have_nxt;
+    // is the item after this one READY? Decided from a snapshot wave 0 wrote during the PREVIOUS iteration: every wave takes the same branch
+    const bool nxt_ready = c == cur.NC - 2 && rfl(snap[itn & 1u]) != 0;
+    if (wave == 0) control_issue();
+    TSTAMP(0)
+    Epi ep = {};
+    if (last) ep = load_epi(cur);
+    TSTAMP(1)
+    // the chunk that is staged while this one is multiplied: the item's next chunk, or chunk 0 of the next item, or nothing
+    const bool stg = !last || pre;
+    const int sc = last ? 0 : c + 1;
+    const unsigned sst = lds0 + (stage ^ 1u) * G::STAGE;
     const unsigned char* sb = smem + stage * G::STAGE;
-    if (cur.NT == 2) chunk(sb, std::integral_constant<int, 4>{});
-    else chunk(sb, std::integral_constant<int, 2>{});
+    auto between = [&](int step) { if (stg) dma_piece(last ? nxt : cur, sc, sst, step); };
+    if (cur.NT == 2) chunk(sb, std::integral_constant<int, 4>{}, between);
+    else chunk(sb, std::integral_constant<int, 2>{}, between);
+    TSTAMP(2)
+    if (nxt_ready) {                               // the item's last chunk has been requested: the staging registers now describe the NEXT item
+      nxt = load_item(ck + 1);                     // (its descriptor reads and scalar loads overlap the wait below instead of leading the last iteration)
+      setup_dma(nxt);
+      have_nxt = true;
+    }
     if (last) {
-      if (!(FFP_TRUNK_DBG && (a.dbg & 1))) epilogue(cur);
+      if (!(FFP_TRUNK_SKIP & 1)) epilogue(cur, ep);
+      TSTAMP(3)
       // this wave's DMA pieces are older than the epilogue's loads and stores: all but the 4 NT stores must have completed
       if (cur.NT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
       wait_all();
+      if (wave == 0) control_consume();            // everything this wave has asked for is back (the full wait above)
     }
+    if (tid == 0) {
+      const int nseq = pre ? ck + 2 : ck + 1;      // the item that will be "next" in the following iteration
+      snap[(itn + 1u) & 1u] = get4(s_st, nseq & 3) == D_READY ? 1 : 0;
+    }
+    TSTAMP(4)
     __syncthreads();
+    TSTAMP(5)
+#if FFP_TRUNK_DBG
+    ++n_iter;
+#endif
     if (pub_tile >= 0) {                           // the previous item: its stores were drained by this (non-final) chunk's full wait
       publish(pub_tile, pub_layer);
       pub_tile = -1;
     }
     if (!last) { ++c; stage ^= 1u; continue; }
     if (tid == 0) desc[(ck & 3) * 16] = D_EMPTY;   // the finished item's slot: sequence ck + 4 will be fetched into it
+    if (wave == 0) put4(s_st, ck & 3, D_EMPTY);
+    have_nxt = false;
     if (pre) {
       pub_tile = cur.tile; pub_layer = cur.layer;
       cur = nxt; ++ck; c = 0; stage ^= 1u;
-      init_acc(cur);
+      init_acc(cur, smem + stage * G::STAGE);
       continue;
     }
     // the next item is not ready (or there is none): finish this one for good, then wait for it
@@ -463,17 +538,21 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
     publish(cur.tile, cur.layer);
     if (wave == 0) control_wait(ck + 1);
     __syncthreads();
-    if (rfl(desc[((ck + 1) & 3) * 16]) != D_READY) return;
+    if (rfl(desc[((ck + 1) & 3) * 16]) != D_READY) { TDUMP() return; }
     ++ck;
     cur = load_item(ck);
     setup_dma(cur);
     stage ^= 1u;
     issue_dma(cur, 0, lds0 + stage * G::STAGE);
-    init_acc(cur);
     if (tid == 0) { snap[0] = 0; snap[1] = 0; }
     wait_all();
     __syncthreads();
+    init_acc(cur, smem + stage * G::STAGE);
     c = 0;
+#if FFP_TRUNK_DBG
+    ++n_slow;
+#endif
+    TSTAMP(6)
   }
 }
 
@@ -527,12 +606,11 @@ void TrunkPlan::launch(hipStream_t st, int dbg) {
   using G = TG;
   TrunkArgs a{};
   int n_tiles = 0;
-  a.tiles = lvl->tile_table(G::TH, &n_tiles, &a.n_tiles_dev, st);
+  a.tiles = lvl->tile_table_packed(G::TH, &n_tiles, &a.n_tiles_dev, st);
   if (n_tiles == 0) return;
   a.ntiles_host = n_tiles;
   a.layers = d_layers.as<TrunkLayer>();
   a.n_layers = n_layers;
-  a.img_tab = lvl->d_tab.as<int4>();
   // [queue head, error word, padding to 64 B | done[tiles]]: zeroed before EVERY launch (a memset node under graph replay)
   const size_t need = 64 + sizeof(unsigned) * (size_t)n_tiles;
   const size_t nb = (need + 63) / 64 * 64;
@@ -553,7 +631,7 @@ void TrunkPlan::launch(hipStream_t st, int dbg) {
     unsigned h[16];
     FFP_HIP(hipMemcpyAsync(h, sync.p, sizeof(h), hipMemcpyDeviceToHost, st));
     FFP_HIP(hipStreamSynchronize(st));
-    fprintf(stderr, "trunk launch: tiles %d layers %d grid %u | head %u err %u |", n_tiles, n_layers, grid, h[0], h[1]);
+    fprintf(stderr, "trunk launch: tiles %d layers %d grid %u | head %u err %u | per iteration, wave 0 then wave 1: control, next-item set-up, chunk, epilogue, wait, barrier, slow path (per iteration); last word: iterations | slow paths << 16 |", n_tiles, n_layers, grid, h[0], h[1]);
     for (int i = 2; i < 16; ++i) fprintf(stderr, " %u", h[i]);
     fprintf(stderr, "\n");
   }

@@ -24,8 +24,8 @@ struct TrunkArgs {
   int n_layers;
   int ntiles_host;
   const int* n_tiles_dev;    // capacity-mode levels: the batch's tile count (see ConvArgs)
-  const int4* tiles;         // {image, y0, x0, tiles_x | tiles_y << 16} per 32 x 16 tile, images' tiles row-major and consecutive
-  const int4* img_tab;       // level table {first pixel, h, w, 0}
+  const int4* tiles;         // Level::tile_table_packed(32): {first pixel of the image, y0 | x0 << 16, h | w << 16, tile columns | rows << 16} per 32 x 16 tile,
+                             // the tiles of an image row-major and consecutive
   unsigned* queue;           // [0] next item, [1] error word (a dependency wait that gave up)
   unsigned* done;            // [tile] layers completed
   int dbg;
