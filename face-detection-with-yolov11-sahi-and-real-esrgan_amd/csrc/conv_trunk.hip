@@ -49,11 +49,12 @@ struct TG {
   static constexpr int TH = 32;                               // tile rows (tile columns: 16)
   static constexpr int HR = TH + 2, HC = 18;                  // halo rows / columns
   static constexpr int PIX_PIECES = 39;                       // 34 x 18 = 612 halo pixels x 64 B = 38.25 KiB -> 39 pieces of 1 KiB (12 dummy pixels)
-  static constexpr int PIX = 40 * 1024;                       // pixel area of a stage (one spare piece keeps the weight area 1 KiB aligned)
-  static constexpr int WB = 18 * 1024;                        // weight fragments of one 32-channel block and chunk: [tap][M-tile][lane] x 16 B
-  static constexpr int STAGE = PIX + 2 * WB;                  // 77,824
-  static constexpr int MISC = 2 * STAGE;                      // descriptor ring + control words
-  static constexpr int LDS = MISC + 4 * 64 + 64;              // 155,968 B
+  static constexpr int PIX = PIX_PIECES * 1024;               // one pixel stage (a 32-channel chunk of the halo tile)
+  static constexpr int WB = 18 * 1024;                        // one weight stage: the fragments of one 32-channel block and chunk, [tap][M-tile][lane] x 16 B
+  static constexpr int WOFF = 3 * PIX;                        // LDS: [3 pixel stages][2 weight stages][descriptor ring, snapshot words][2 bias slots]
+  static constexpr int MISC = WOFF + 2 * WB;                  // 156,672
+  static constexpr int BIAS = MISC + 4 * 64 + 64;             // 2 x 256 B
+  static constexpr int LDS = BIAS + 2 * 256;                  // 157,504 B: one workgroup per CU
   static constexpr int ROWB = HC * 64;                        // bytes of a halo row
 };
 
@@ -80,6 +81,10 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base, unsigned bytes) {
 // range, the lane's 16 bytes are zeros. M0 carries the LDS address and is restored (compiler-reserved).
 template <bool SC1> __device__ __forceinline__ void dma16(u32x4 rs, unsigned voff, unsigned soff, unsigned lds) {
   unsigned keep;
+  // the descriptor, the scalar offset and the LDS address are wave-uniform by construction; where hipcc's uniformity analysis cannot see it
+  // (values merged over the walk's loop) it would hand the asm statement vector registers: say so once more (folds away where it is known)
+  rs[0] = rfl(rs[0]); rs[1] = rfl(rs[1]); rs[2] = rfl(rs[2]); rs[3] = rfl(rs[3]);
+  soff = rfl(soff); lds = rfl(lds);
   if constexpr (SC1)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %4 offen sc1 lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds), "s"(soff) : "memory");
@@ -114,7 +119,7 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
   constexpr unsigned OOB = 0xFFFFFFFFu;
   constexpr int AUXC = COH ? 16 : 0;                          // sc1 on activation loads / stores of a multi-layer launch
 
-  unsigned isrc[5];        // byte offset of the lane's 16 bytes of chunk 0 from the image's first pixel record (+ in_coff), or OOB
+  unsigned isrc[6];        // byte offset of the lane's 16 bytes of chunk 0 from the image's first pixel record (+ in_coff), or OOB
 
   // fragment read offsets: halo rows 4 * wave + j (j = 0..5), column pc + kx, slot g
   unsigned boff[3];
@@ -123,7 +128,6 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
     const int hx = pc + kx;
     boff[kx] = (unsigned)(((4 * wave) * G::HC + hx) * 64 + ((g ^ ((hx >> 1) & 2)) << 4));
   }
-  const unsigned aoff = G::PIX + lane * 16;
 
   // ---- control (wave 0): the queue, the tile entries and the dependency counters of the next three items, one step per chunk -------------
   int ck = -1;             // sequence number (within this workgroup) of the CURRENT item (-1: none yet); slot = seq & 3
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
   if (tid < 80) desc[tid] = 0;
   __syncthreads();
 
-  // ---- item set-up: descriptor slot -> SGPRs, per-lane source offsets of the halo pixels ------------------------------------------------
+  // ---- item set-up: descriptor slot -> SGPRs ------------------------------------------------------------------------------------------------
   auto load_item = [&](int sq) {
     const int4 d0 = *reinterpret_cast<const int4*>(desc + (sq & 3) * 16), d1 = *reinterpret_cast<const int4*>(desc + (sq & 3) * 16 + 4);
     Item it;
@@ -258,50 +262,75 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
     it.NT = layers[it.layer].cout >> 5;
     return it;
   };
-  u32x4 rs_in, rs_w, rs_b;
-  auto setup_dma = [&](const Item& it) {
+  // ---- staging. The workgroup's work is ONE STREAM OF STEPS: step = (item, 32-channel input chunk c, 32-channel output block nt), 72 MFMAs per
+  // wave. A step multiplies the chunk's halo tile (pixel stage = chunk index in the stream % 3) by one block's weight fragments (weight stage
+  // = step index % 2). While it runs, the NEXT step's weights and the pixel chunk TWO chunks ahead are requested by LDS-DMA — across items:
+  // the stream runs into the next item as soon as that item is known and its dependencies are met. A 64-channel layer takes two steps per
+  // chunk over the same pixel stage.
+  u32x4 rs_in, rs_w, rs_b;                         // pixel source (the item `pix_item` describes), weight / bias source (the item of the weight cursor)
+  int pix_item = -1;                               // sequence number of the item isrc[] / rs_in describe (-1: none)
+  int w_NC = 0;                                    // chunks of the weight cursor's layer
+  auto setup_pix = [&](const Item& it, int seq) {
     const LPtr L = layers + it.layer;
     const int cs = L->in_cs;
     const unsigned char* inb = reinterpret_cast<const unsigned char*>(L->in) + ((long long)it.px0 * cs + L->in_coff) * 2;
     rs_in = make_rsrc(inb, 0x7FFFFFF0u);
-    rs_w = make_rsrc(L->wpk, (unsigned)(it.NT * it.NC * G::WB));
-    rs_b = make_rsrc(L->bias, (unsigned)(it.NT * 128));
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {                    // pixel piece wave + 8 i: lane -> halo pixel q = piece * 16 + lane / 4, LDS slot position lane % 4
-      const int p = wave + 8 * i;
-      const int q = p * 16 + (lane >> 2);
+    for (int i = 0; i < 6; ++i) {                    // pixel piece (wave - 1) + 7 i of the 39 (waves 1..7; wave 0 stages no pixels: see pix_pieces())
+      const int p = wave - 1 + 7 * i;
+      const int q = p * 16 + (lane >> 2);            // lane -> halo pixel q = piece * 16 + lane / 4, LDS slot position lane % 4
       const int hy = (q * 3641) >> 16, hx = q - hy * G::HC;          // q / 18 for q < 640
       const int sl = (lane & 3) ^ ((hx >> 1) & 2);                   // which holds SOURCE slot (lane % 4) ^ ((hx >> 1) & 2): conflict-free fragment reads
       const int iy = it.y0 - 1 + hy, ix = it.x0 - 1 + hx;
-      const bool ok = p < G::PIX_PIECES && q < G::HR * G::HC && (unsigned)iy < (unsigned)it.H && (unsigned)ix < (unsigned)it.W;
+      const bool ok = wave > 0 && p < G::PIX_PIECES && q < G::HR * G::HC && (unsigned)iy < (unsigned)it.H && (unsigned)ix < (unsigned)it.W;
       isrc[i] = ok ? (unsigned)((iy * it.W + ix) * cs * 2 + sl * 16) : OOB;
     }
+    pix_item = seq;
   };
-  // chunk c of the item -> stage at LDS byte address `st`: <= 5 pixel pieces + <= 3 (5) weight pieces per wave, issued as ten STEPS (one per
-  // MFMA step of the chunk being multiplied, so that the instructions' issue time — 60-185 cycles each while the address unit is busy —
-  // sits in the matrix instructions' shadow instead of in front of them). The chunk's 64 bytes per pixel ride in the scalar offset.
-  auto dma_piece = [&](const Item& it, int c, unsigned st, int step) {
+  auto setup_w = [&](const Item& it) {
+    const LPtr L = layers + it.layer;
+    rs_w = make_rsrc(L->wpk, (unsigned)(it.NT * it.NC * G::WB));
+    rs_b = make_rsrc(L->bias, (unsigned)(it.NT * 128));
+    w_NC = it.NC;
+  };
+  // one wave-piece (64 lanes x 16 B) per call. Pixel chunk c of the item isrc[] describes -> pixel stage at LDS address `st`: pieces wave + 8 i.
+  // Wave 0 stages NO pixel pieces: its vector-memory queue then holds nothing younger than its control requests and weight pieces at the end
+  // of a step, so reading the control answers (a full vmcnt(0) as far as hipcc can tell) waits for nothing that is still meant to be in flight.
+  auto dma_pix = [&](int c, unsigned st, int i) {
     if ((FFP_TRUNK_SKIP & 4)) return;
-    if (step < 5) {
-      if (wave + 8 * step < G::PIX_PIECES) dma16<COH>(rs_in, isrc[step], (unsigned)(c * 64), st + (unsigned)((wave + 8 * step) << 10));
-      else if (c == 0) dma16<false>(rs_b, (unsigned)lane * 16u, 0u, st + (unsigned)(G::PIX_PIECES << 10));   // the layer's bias: piece 39 of chunk 0's stage (wave 7)
-    } else {
-      const int q = wave + 8 * (step - 5);
-      if (q < it.NT * 18) {
-        const int nt = q >= 18 ? 1 : 0, pq = q - nt * 18;
-        dma16<false>(rs_w, (unsigned)lane * 16u, (unsigned)(((nt * it.NC + c) * 18 + pq) << 10), st + (unsigned)(G::PIX + (q << 10)));
-      }
+    const int p = wave - 1 + 7 * i;
+    if (wave > 0 && p < G::PIX_PIECES) dma16<COH>(rs_in, isrc[i], (unsigned)(c * 64), st + (unsigned)(p << 10));
+  };
+  const int pix_pieces = wave == 0 ? 0 : (wave <= 4 ? 6 : 5);           // 39 = 4 x 6 + 3 x 5
+  // wait until at most `keep` of this wave's vector-memory operations are outstanding (the youngest ones: a step's pixel pieces are requested
+  // last and belong to the chunk two chunks ahead — they are NOT waited for at the end of the step that requests them)
+  auto wait_keep = [&](int keep) {
+    switch (keep) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
   };
-  auto issue_dma = [&](const Item& it, int c, unsigned st) {
-#pragma unroll
-    for (int step = 0; step < 10; ++step) dma_piece(it, c, st, step);
+  // weight fragments of (chunk c, block nt) of the weight cursor's layer -> weight stage at `st`: pieces wave + 8 j < 18; with first = true
+  // also the layer's bias (256 B, wave 7's third slot) -> bias slot at `bst`
+  auto dma_w = [&](int c, int nt, unsigned st, int j, bool first, unsigned bst) {
+    if ((FFP_TRUNK_SKIP & 4)) return;
+    const int q = wave + 8 * j;
+    if (q < 18) dma16<false>(rs_w, (unsigned)lane * 16u, (unsigned)(((nt * w_NC + c) * 18 + q) << 10), st + (unsigned)(q << 10));
+    else if (first && q == 23) dma16<false>(rs_b, lane < 16 ? (unsigned)lane * 16u : OOB, 0u, bst);
   };
 
-  // ---- arithmetic: conv_rows16_kernel's chunk, for NM = 2 NT M-tiles -----------------------------------------------------------------------
+  // ---- arithmetic: conv_rows16_kernel's chunk for ONE 32-channel output block, always on the FRONT accumulators acc[.][0], acc[.][1]. A 64-channel
+  // layer keeps its second block in acc[.][2], acc[.][3] and swaps the two sets between steps (32 v_swap per step, ~4 % of it): ONE instance of
+  // the 72-MFMA body instead of two — with two, hipcc ran out of registers at the merge of the two paths (70 spilled, 8 of them inside the stream).
   f32x4 acc[4][4];
-  auto init_acc = [&](const Item& it, const unsigned char* sb) {      // the bias came with chunk 0's stage (piece 39): no global load at an item's start
-    const float* b = reinterpret_cast<const float*>(sb + (G::PIX_PIECES << 10));
+  auto init_acc = [&](const Item& it, const unsigned char* bias) {      // the bias came by DMA with the item's first weight stage: no global load at an item's start
+    const float* b = reinterpret_cast<const float*>(bias);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       if (nt < it.NT) {
@@ -315,26 +344,31 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
       }
     }
   };
-  auto chunk = [&](const unsigned char* sb, auto nm_tag, auto&& between) {
-    constexpr int NM = decltype(nm_tag)::value;
+  auto swap_blocks = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) { const f32x4 t = acc[i][m]; acc[i][m] = acc[i][2 + m]; acc[i][2 + m] = t; }
+  };
+  auto chunk = [&](const unsigned char* sp, const unsigned char* sw, auto&& between) {
     // Input-row fragments in EIGHT rolling slots instead of two sets of six: fragment (kx, row r) lives in slot (r + 6 kx) % 8 and is read
     // from LDS at least one step before its first MFMA, into a slot whose previous row is dead (row r of a kx serves the steps ky = r - 3 .. r):
     //   step 0: (1,0) (1,1) | 1: (1,2) | 2: (1,3) | 3: (1,4) (1,5) | 4: (2,0) (2,1) (2,2) | 5: (2,3) | 6: (2,4) (2,5)
-    // 16 registers fewer than the double set; the weight fragments are one step ahead (a step is 8 or 16 MFMAs: 128 / 256 cycles of cover).
-    uint4 bq[8] = {}, aq[2][NM] = {};
+    // 16 registers fewer than the double set; the weight fragments are one step ahead (a step is 8 MFMAs: 128 cycles of cover, 256 with the partner wave).
+    uint4 bq[8] = {}, aq[2][2] = {};
     auto ldB1 = [&](int kx, int r) {
       if ((FFP_TRUNK_SKIP & 16)) { asm volatile("" : "+v"(bq[(r + 6 * kx) & 7].x), "+v"(bq[(r + 6 * kx) & 7].y), "+v"(bq[(r + 6 * kx) & 7].z), "+v"(bq[(r + 6 * kx) & 7].w)); return; }
-      bq[(r + 6 * kx) & 7] = *reinterpret_cast<const uint4*>(sb + boff[kx] + r * G::ROWB);
+      bq[(r + 6 * kx) & 7] = *reinterpret_cast<const uint4*>(sp + boff[kx] + r * G::ROWB);
     };
     auto ldA = [&](int s, int q) {
       const int tap = (s % 3) * 3 + s / 3;
       if ((FFP_TRUNK_SKIP & 16)) {
 #pragma unroll
-        for (int mm = 0; mm < NM; ++mm) asm volatile("" : "+v"(aq[q][mm].x), "+v"(aq[q][mm].y), "+v"(aq[q][mm].z), "+v"(aq[q][mm].w));
+        for (int m = 0; m < 2; ++m) asm volatile("" : "+v"(aq[q][m].x), "+v"(aq[q][m].y), "+v"(aq[q][m].z), "+v"(aq[q][m].w));
         return;
       }
 #pragma unroll
-      for (int mm = 0; mm < NM; ++mm) aq[q][mm] = *reinterpret_cast<const uint4*>(sb + aoff + (((mm >> 1) * 18 + tap * 2 + (mm & 1)) << 10));
+      for (int m = 0; m < 2; ++m) aq[q][m] = *reinterpret_cast<const uint4*>(sw + lane * 16 + ((tap * 2 + m) << 10));
     };
 #pragma unroll
     for (int r = 0; r < 6; ++r) ldB1(0, r);
@@ -352,18 +386,17 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
       if (s == 5) ldB1(2, 3);
       if (s == 6) { ldB1(2, 4); ldB1(2, 5); }
       between(s);
-      if (s == 8) between(9);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int mm = 0; mm < NM; ++mm) {
+        for (int m = 0; m < 2; ++m) {
           if ((FFP_TRUNK_SKIP & 2)) continue;
           union { uint4 u; f16x8 h; } ua, ub;
-          ua.u = aq[s & 1][mm]; ub.u = bq[(i + ky + 6 * kx) & 7];
-          acc[i][mm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ua.h, ub.h, acc[i][mm], 0, 0, 0);
+          ua.u = aq[s & 1][m]; ub.u = bq[(i + ky + 6 * kx) & 7];
+          acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ua.h, ub.h, acc[i][m], 0, 0, 0);
         }
 #pragma unroll
-      for (int r = 0; r < 4 * NM; ++r) {
+      for (int r = 0; r < 8; ++r) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
         __builtin_amdgcn_sched_group_barrier(0x7F6, 1, 0);     // one other instruction
       }
@@ -372,7 +405,7 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
   };
 
   // ---- epilogue: lane (pc, g) holds channels 32 nt + 8 g .. + 7 of pixel (row 4 * wave + i, column pc); 4 NT stores per wave -----------------
-  struct Epi {             // the epilogue's layer parameters (scalar loads issued BEFORE the last chunk's MFMAs: their latency is off the item's tail)
+  struct Epi {             // the epilogue's layer parameters (scalar loads issued BEFORE the last step's MFMAs: their latency is off the item's tail)
     const unsigned char *ob, *r1b, *r2b;
     int act, o_cs, r1_cs, r2_cs;
     float s1, s2;
@@ -404,6 +437,8 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       if (nt >= it.NT) break;
+      // one 32-channel block at a time: hipcc otherwise hoists the residual loads of all eight (row, block) pairs (64 registers)
+      __builtin_amdgcn_sched_barrier(0);
       const int ch0 = nt * 32 + 8 * g;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -414,8 +449,10 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
         if (has1) r1v = __builtin_amdgcn_raw_buffer_load_b128(rs_r1, ok ? (rel * r1_cs + ch0) * 2 : OOB, 0, AUXC);
         if (has2) r2v = __builtin_amdgcn_raw_buffer_load_b128(rs_r2, ok ? (rel * r2_cs + ch0) * 2 : OOB, 0, AUXC);
         float v[8];
-        v[0] = acc[i][nt * 2][0]; v[1] = acc[i][nt * 2][1]; v[2] = acc[i][nt * 2][2]; v[3] = acc[i][nt * 2][3];
-        v[4] = acc[i][nt * 2 + 1][0]; v[5] = acc[i][nt * 2 + 1][1]; v[6] = acc[i][nt * 2 + 1][2]; v[7] = acc[i][nt * 2 + 1][3];
+        // where block nt's sums are after the item's last step: a 64-channel layer ends on block 1, so block 0 sits in the back set
+        const f32x4 a0 = it.NT == 2 ? acc[i][2 - 2 * nt] : acc[i][0], a1 = it.NT == 2 ? acc[i][3 - 2 * nt] : acc[i][1];
+        v[0] = a0[0]; v[1] = a0[1]; v[2] = a0[2]; v[3] = a0[3];
+        v[4] = a1[0]; v[5] = a1[1]; v[6] = a1[2]; v[7] = a1[3];
         if (act == ACT_LRELU) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], v[q] * 0.2f);
@@ -446,70 +483,118 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
   };
   auto wait_all = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
-  // ---- prologue: the first item --------------------------------------------------------------------------------------------------------------
+  // ---- the walk --------------------------------------------------------------------------------------------------------------------------------
   if (wave == 0) control_wait(0);
   __syncthreads();
   if (rfl(desc[0]) != D_READY) return;
   ck = 0;
-  Item cur = load_item(0);
-  setup_dma(cur);
-  issue_dma(cur, 0, lds0);
-  wait_all();
-  __syncthreads();
-  init_acc(cur, smem);
-  int c = 0;
-  unsigned stage = 0;
+  Item cur = load_item(0), nxt = cur;
+  bool have_nxt = false;
+  int c = 0, nt = 0;
+  unsigned sidx = 0;       // step index in the stream: weight stage = sidx & 1
+  unsigned pq = 0;         // chunk index in the stream of the chunk being multiplied: pixel stage = pq % 3
+  unsigned pix_next = 0;   // chunk index in the stream of the next pixel chunk to request (pix_next > pq: this chunk is in LDS or on its way)
+  unsigned pix_base = 0;   // chunk index in the stream of the current item's chunk 0
+  bool w_have = false;     // this step's weights have been requested (in the previous step)
   int pub_tile = -1, pub_layer = 0;
-  // One iteration = one chunk. Whether the NEXT item can be prefetched is decided from a snapshot that wave 0 wrote during the PREVIOUS
-  // iteration (snap[parity]): every wave of the workgroup takes the same branch, whatever wave 0's control step is doing meanwhile.
+  auto pstage = [&](unsigned n) { return lds0 + (n % 3u) * G::PIX; };
+  // which (item, chunk) is chunk index n of the stream? 0: the current item, 1: the next one, -1: not known yet
+  auto chunk_of = [&](unsigned n, int& cc) {
+    const int o = (int)(n - pix_base);
+    if (o < cur.NC) { cc = o; return 0; }
+    if (have_nxt && o - cur.NC < nxt.NC) { cc = o - cur.NC; return 1; }
+    cc = 0;
+    return -1;
+  };
 #if FFP_TRUNK_DBG
-  unsigned long long tsum[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();      // control, next-item set-up, chunk, epilogue, wait, barrier, slow path
+  unsigned long long tsum[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();      // control, epilogue parameters, step, epilogue + next-item set-up, wait, barrier, synchronous staging
   unsigned n_iter = 0, n_slow = 0;
 #define TSTAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsum[k] += t_ - tprev; tprev = t_; }
 #define TDUMP() if (blockIdx.x == 0 && lane == 0 && wave < 2) { unsigned* o = a.queue + 2 + wave * 7; for (int k_ = 0; k_ < 7; ++k_) o[k_] = (unsigned)(tsum[k_] / (n_iter ? n_iter : 1)); \
-                  if (wave == 0) { a.queue[1] = 0; } if (wave == 1) { o[6] = n_iter | (n_slow << 16); } }
+                  if (wave == 1) { o[6] = n_iter | (n_slow << 16); } }
 #else
 #define TSTAMP(k)
 #define TDUMP()
 #endif
-  bool have_nxt = false;
-  Item nxt = cur;
   for (unsigned itn = 0;; ++itn) {
-    const bool last = c == cur.NC - 1;
-    const bool pre = last && have_nxt;
-    // is the item after this one READY? Decided from a snapshot wave 0 wrote during the PREVIOUS iteration: every wave takes the same branch
-    const bool nxt_ready = c == cur.NC - 2 && rfl(snap[itn & 1u]) != 0;
+    // ---- operands of this step not requested yet (the walk's first step, after a late dependency, after a gap in the look-ahead): request them
+    // now — and as much of the look-ahead as is known — and wait. Every wave takes the same branch (the cursors are wave-uniform).
+    if (pix_next <= pq || !w_have) {
+      while (pix_next <= pq + 2) {
+        int cc;
+        const int which = chunk_of(pix_next, cc);
+        if (which < 0) break;
+        const int seq = ck + which;
+        if (pix_item != seq) setup_pix(which ? nxt : cur, seq);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dma_pix(cc, pstage(pix_next), i);
+        ++pix_next;
+      }
+      if (!w_have) {
+        setup_w(cur);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dma_w(c, nt, lds0 + G::WOFF + (sidx & 1u) * G::WB, j, c == 0 && nt == 0, lds0 + G::BIAS + (unsigned)(ck & 1) * 256u);
+        w_have = true;
+      }
+      wait_all();
+      __syncthreads();
+      if (c == 0 && nt == 0) init_acc(cur, smem + G::BIAS + (ck & 1) * 256);
+#if FFP_TRUNK_DBG
+      ++n_slow;
+#endif
+      TSTAMP(6)
+    }
+    const bool last = c == cur.NC - 1 && nt == cur.NT - 1;       // the item's last step
+    const bool nxt_known = rfl(snap[itn & 1u]) != 0;             // is the item after this one READY? (wave 0's snapshot of the PREVIOUS iteration: uniform)
     if (wave == 0) control_issue();
     TSTAMP(0)
     Epi ep = {};
     if (last) ep = load_epi(cur);
     TSTAMP(1)
-    // the chunk that is staged while this one is multiplied: the item's next chunk, or chunk 0 of the next item, or nothing
-    const bool stg = !last || pre;
-    const int sc = last ? 0 : c + 1;
-    const unsigned sst = lds0 + (stage ^ 1u) * G::STAGE;
-    const unsigned char* sb = smem + stage * G::STAGE;
-    auto between = [&](int step) { if (stg) dma_piece(last ? nxt : cur, sc, sst, step); };
-    if (cur.NT == 2) chunk(sb, std::integral_constant<int, 4>{}, between);
-    else chunk(sb, std::integral_constant<int, 2>{}, between);
+    // ---- what is requested while this step multiplies: the next step's weights (this item's, or the next item's first) ...
+    int wc = c, wnt = nt + 1, wwhich = 0;
+    if (wnt == cur.NT) { wnt = 0; ++wc; }
+    if (wc == cur.NC) { wc = 0; wwhich = have_nxt ? 1 : -1; }
+    const bool w_first = wwhich == 1;                            // the next item's first step: its bias rides along
+    if (wwhich == 1) setup_w(nxt);                               // (scalar loads; this item's weight cursor has no further use for rs_w)
+    const unsigned wst = lds0 + G::WOFF + ((sidx + 1u) & 1u) * G::WB, bst = lds0 + G::BIAS + (unsigned)((ck + 1) & 1) * 256u;
+    // ... and ONE pixel chunk, up to two chunks ahead of the one being multiplied (only in a chunk's first step)
+    int pcc = 0, pwhich = -1;
+    if (nt == 0 && pix_next <= pq + 2) pwhich = chunk_of(pix_next, pcc);
+    if (pwhich >= 0 && pix_item != ck + pwhich) setup_pix(pwhich ? nxt : cur, ck + pwhich);
+    const unsigned p_idx = pix_next, pst = pstage(pix_next);
+    auto between = [&](int step) {                               // MFMA step 0..8 of this step: weights first (needed one step from now), then the pixel pieces
+      if (step < 3) { if (wwhich >= 0) dma_w(wc, wnt, wst, step, w_first, bst); }
+      else { if (pwhich >= 0) dma_pix(pcc, pst, step - 3); }            // steps 3..8: six slots
+    };
+    const unsigned char* sp = smem + (pq % 3u) * G::PIX;
+    const unsigned char* sw = smem + G::WOFF + (sidx & 1u) * G::WB;
+    chunk(sp, sw, between);
+    if (cur.NT == 2 && !last) swap_blocks();                    // the other block's sums to the front for the next step (after the last step: block 1 in front)
+    if (pwhich >= 0) ++pix_next;
+    const bool w_next_have = wwhich >= 0;
     TSTAMP(2)
-    if (nxt_ready) {                               // the item's last chunk has been requested: the staging registers now describe the NEXT item
-      nxt = load_item(ck + 1);                     // (its descriptor reads and scalar loads overlap the wait below instead of leading the last iteration)
-      setup_dma(nxt);
-      have_nxt = true;
-    }
     if (last) {
       if (!(FFP_TRUNK_SKIP & 1)) epilogue(cur, ep);
-      TSTAMP(3)
-      // this wave's DMA pieces are older than the epilogue's loads and stores: all but the 4 NT stores must have completed
-      if (cur.NT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      wait_all();
-      if (wave == 0) control_consume();            // everything this wave has asked for is back (the full wait above)
     }
-    if (tid == 0) {
-      const int nseq = pre ? ck + 2 : ck + 1;      // the item that will be "next" in the following iteration
+    if (!have_nxt && nxt_known) {                  // the next item's descriptor (LDS reads + scalar loads: they overlap the wait below)
+      nxt = load_item(ck + 1);
+      have_nxt = true;
+    }
+    TSTAMP(3)
+    // the end of the step: the next step's weights (requested first) must be in LDS; this step's pixel pieces (requested after them, for the chunk
+    // two chunks ahead) and the epilogue's 4 NT stores (younger still) stay in flight
+    // (only when that chunk really is two ahead: after a gap in the look-ahead the chunk requested here is the NEXT one and must land now)
+    const int npix = (pwhich >= 0 && p_idx == pq + 2u) ? pix_pieces : 0;
+    if (last) {
+      wait_keep(npix + 4 * cur.NT);
+    } else {
+      wait_keep(npix);
+      if (wave == 0) control_consume();            // wave 0: npix = 0, everything it has asked for is back
+    }
+    const bool switching = last && w_next_have;    // the stream runs on into the next item
+    if (tid == 0) {                                // is the item after the ones this workgroup will hold in the next iteration READY?
+      const int nseq = switching ? ck + 2 : ck + 1;
       snap[(itn + 1u) & 1u] = get4(s_st, nseq & 3) == D_READY ? 1 : 0;
     }
     TSTAMP(4)
@@ -518,41 +603,48 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
 #if FFP_TRUNK_DBG
     ++n_iter;
 #endif
-    if (pub_tile >= 0) {                           // the previous item: its stores were drained by this (non-final) chunk's full wait
+    if (pub_tile >= 0 && !last) {                  // the previous item: its stores were drained by this (non-final) step's full wait
       publish(pub_tile, pub_layer);
       pub_tile = -1;
     }
-    if (!last) { ++c; stage ^= 1u; continue; }
-    if (tid == 0) desc[(ck & 3) * 16] = D_EMPTY;   // the finished item's slot: sequence ck + 4 will be fetched into it
-    if (wave == 0) put4(s_st, ck & 3, D_EMPTY);
-    have_nxt = false;
-    if (pre) {
-      pub_tile = cur.tile; pub_layer = cur.layer;
-      cur = nxt; ++ck; c = 0; stage ^= 1u;
-      init_acc(cur, smem + stage * G::STAGE);
+    ++sidx;
+    w_have = w_next_have;
+    if (!last) {
+      if (++nt == cur.NT) { nt = 0; ++c; ++pq; }
       continue;
     }
-    // the next item is not ready (or there is none): finish this one for good, then wait for it
+    // ---- the item is finished
+    if (tid == 0) desc[(ck & 3) * 16] = D_EMPTY;   // its slot: sequence ck + 4 will be fetched into it
+    if (wave == 0) put4(s_st, ck & 3, D_EMPTY);
+    ++pq;
+    pix_base += (unsigned)cur.NC;
+    nt = 0; c = 0;
+    if (switching) {
+      if (pub_tile >= 0) {                         // (an item of ONE step cannot occur: cin >= 64; kept for safety) drain and publish the older one now
+        wait_all();
+        __syncthreads();
+        publish(pub_tile, pub_layer);
+      }
+      pub_tile = cur.tile; pub_layer = cur.layer;
+      cur = nxt; have_nxt = false; ++ck;
+      init_acc(cur, smem + G::BIAS + (ck & 1) * 256);
+      continue;
+    }
+    // the next item is not known or not ready (or there is none): finish this one for good, then wait for it
     wait_all();
     __syncthreads();
+    if (pub_tile >= 0) { publish(pub_tile, pub_layer); pub_tile = -1; }
     publish(cur.tile, cur.layer);
     if (wave == 0) control_wait(ck + 1);
     __syncthreads();
     if (rfl(desc[((ck + 1) & 3) * 16]) != D_READY) { TDUMP() return; }
     ++ck;
     cur = load_item(ck);
-    setup_dma(cur);
-    stage ^= 1u;
-    issue_dma(cur, 0, lds0 + stage * G::STAGE);
+    have_nxt = false;
+    pix_next = pq;                                 // nothing of the new item has been requested: the top of the loop does it and waits
+    w_have = false;
     if (tid == 0) { snap[0] = 0; snap[1] = 0; }
-    wait_all();
     __syncthreads();
-    init_acc(cur, smem + stage * G::STAGE);
-    c = 0;
-#if FFP_TRUNK_DBG
-    ++n_slow;
-#endif
-    TSTAMP(6)
   }
 }
 
