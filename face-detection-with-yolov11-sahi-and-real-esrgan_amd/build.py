@@ -79,6 +79,8 @@ VARIANTS = {
     "trunk_dbg_skip18": (["conv_trunk.hip"], ["-DFFP_TRUNK_DBG=1", "-DFFP_TRUNK_SKIP=18"]),   # stamps without MFMAs and fragment reads: is the end-of-step wait the DMA itself?
     "trunk_dbg_skip4": (["conv_trunk.hip"], ["-DFFP_TRUNK_DBG=1", "-DFFP_TRUNK_SKIP=4"]),     # stamps without DMA
     "trunk_dbg_skip16": (["conv_trunk.hip"], ["-DFFP_TRUNK_DBG=1", "-DFFP_TRUNK_SKIP=16"]),   # stamps without fragment reads
+    "trunk_skip1": (["conv_trunk.hip"], ["-DFFP_TRUNK_SKIP=1"]),            # no epilogue (sums kept alive)
+    "trunk_skip5": (["conv_trunk.hip"], ["-DFFP_TRUNK_SKIP=5"]),            # no epilogue, no DMA
     "trunk_skip2": (["conv_trunk.hip"], ["-DFFP_TRUNK_SKIP=2"]),            # compile-time phase skips (tools/trunk_phase_probe.py): no MFMA
     "trunk_skip4": (["conv_trunk.hip"], ["-DFFP_TRUNK_SKIP=4"]),            # no DMA
     "trunk_skip16": (["conv_trunk.hip"], ["-DFFP_TRUNK_SKIP=16"]),          # no fragment reads

@@ -1,29 +1,38 @@
 // conv_trunk.hip — the Real-ESRGAN body (every 3x3 fp16 conv of the 69 residual dense blocks: 345 layers) as ONE persistent launch.
 //
-// What round 4 measured first (tools/probes/stage_probe.hip, profiles/r04_staging_rate_probe.txt): the global -> LDS staging rate of a CU
-// scales with the NUMBER OF WAVES that issue loads (~4 B/clk per wave) up to ~32 B/clk per CU on L2 hits and ~23 B/clk out of the Infinity
-// Cache, whatever the prefetch depth, access pattern or load form. conv_rows16_kernel stages 39 KiB per 288 MFMAs = 34 B/clk per CU at
-// the full matrix rate: it is STAGING-BOUND (its phase probe: staging alone 26 us, MFMAs alone 23.6 us, together 43.8 us), and a role
-// split with four producer waves (conv_rows16pc) delivers 12-14 B/clk. So this kernel
-//   * stages fewer bytes per MFMA: one 8-wave workgroup per CU owns a 32 x 16 pixel tile (wave w: rows 4w..4w+3), so a chunk's weight
-//     fragments serve twice the pixels (25 B/clk per CU at the full matrix rate for 32 output channels), and the 64-channel layers (conv5 of
-//     every dense block: 46 % of the body's FLOPs) run BOTH 32-channel blocks over one staged halo tile (16.5 B/clk);
-//   * stages with LDS-DMA (buffer_load_dwordx4 ... lds) issued by ALL EIGHT waves: no staging VGPRs, no ds_write_b128 traffic on the
-//     VGPR -> LDS path, the LDS image is written lane-linear and the bank-conflict-free XOR swizzle is applied to the SOURCE channel slot;
-//     out-of-image lanes use an out-of-range buffer offset (the range check returns zeros: the conv's zero padding);
-//   * walks (layer, tile) items of ALL the layers it is given out of one global queue (an atomic counter, layer-major order): no launch
-//     boundary, no per-layer tail, no per-launch skeleton. Layer l + 1 of a tile needs layer l of the tile and of its eight neighbours in the
-//     same image: `done[tile]` = layers completed (written by one lane after every wave of the workgroup has drained its stores),
-//     polled ahead of time by wave 0 — one small control step per chunk: item ids are fetched three items ahead, their tile entries one
-//     step later, the nine counters of every fetched item every step — so that a dependency never stalls the MFMA stream unless it is
-//     really late (small batches), and then only this workgroup. Items are taken in queue order and depend only on EARLIER items, so
-//     the grid cannot deadlock whatever part of it is resident (a second persistent launch on the device, the detector's kernels).
-//     Activations written inside the launch are stored write-through (sc1) and read with sc1 loads (DMA and residuals): per-CU L1s are
-//     never refreshed and per-XCD L2s are not coherent (MI355X guide, inter-workgroup visibility); weights and tables are read-only.
+// What round 4 measured first (tools/probes/stage_probe.hip, profiles/r04_staging_rate_probe.txt; in-kernel stamps, profiles/r04_trunk_stamps.txt):
+//   * the global -> LDS staging rate of a CU scales with the NUMBER OF WAVES that issue loads (~4 B/clk per wave) up to ~32 B/clk per CU on
+//     L2 hits and ~23 B/clk out of the Infinity Cache, whatever the prefetch depth, access pattern or load form. conv_rows16_kernel stages
+//     39 KiB per 288 MFMAs = 34 B/clk per CU at the full matrix rate: it is STAGING-BOUND (phase probe: staging alone 26 us, MFMAs alone
+//     23.6 us, together 43.8 us), and a role split with four producer waves (conv_rows16pc) delivers 12-14 B/clk;
+//   * an LDS-DMA piece (buffer_load_dwordx4 ... lds, 1 KiB) takes ~230 cycles to ISSUE while the CU's address unit is at that cap, and an
+//     in-order wave's MFMAs wait behind it: a 72-MFMA step took 1,589 cycles without the DMA instructions in its stream and 3,404 with them.
+// So this kernel
+//   * stages fewer bytes per MFMA: one workgroup per CU owns a 32 x 16 pixel tile, so a chunk's weight fragments serve twice the pixels
+//     of conv_rows16's tile: 57 KiB per 576 MFMAs = 25 B/clk per CU at the full matrix rate;
+//   * splits the workgroup's TWELVE waves by role: four COMPUTE waves, one per SIMD, each owning 8 output rows x 16 columns (64 accumulator
+//     registers, 0.46 KiB of fragment reads per MFMA, conv_rows16: 0.5) whose stream is fragment reads + 144 MFMAs per step and nothing
+//     else, and EIGHT LOADER waves that issue every LDS-DMA piece (eight, because the staging rate is per issuing wave) — their issue stalls
+//     stall nobody's MFMAs. (Sixteen waves — eight compute waves of 4 rows — have 128 registers each: hipcc spilled 46-142 of them, and
+//     scratch traffic inside the MFMA stream is one more stalled vector-memory instruction: 179 us against conv_rows16's 96.) No staging VGPRs, no ds_write traffic; the LDS image is written lane-linear and the bank-conflict-free XOR swizzle
+//     is applied to the SOURCE channel slot; out-of-image lanes use an out-of-range buffer offset (zeros: the conv's zero padding);
+//   * is ONE STREAM OF STEPS per workgroup — step = (item, 32-channel input chunk) — over three pixel stages and two weight stages: while
+//     step q multiplies, the loaders request step q + 1's weights and the pixel chunk of step q + 2, across item boundaries;
+//   * walks (layer, tile, 32-channel output block) items of ALL the layers it is given out of one global queue (an atomic counter,
+//     layer-major order): no launch boundary, no per-layer tail, no per-launch skeleton. A 64-channel layer (conv5 of every dense block) is
+//     two items per tile, neighbours in the queue. Layer l + 1 of a tile needs layer l of the tile and of its eight neighbours in the same
+//     image: `done[tile]` counts finished (layer, block) items (one lane's atomic add after every compute wave has drained its stores),
+//     polled ahead of time by wave 0 — ids are fetched three items ahead, their tile entries one step later, the nine counters of every
+//     fetched item every step, each request consumed one step after it was issued — so that a dependency never stalls the MFMA stream
+//     unless it is really late (small batches), and then only this workgroup. Items are taken in queue order and depend only on
+//     EARLIER items: the grid cannot deadlock whatever part of it is resident (a second persistent launch on the device, the detector's
+//     kernels). Activations written inside the launch are stored write-through (sc1) and read with sc1 loads (DMA and residuals):
+//     per-CU L1s are never refreshed and per-XCD L2s are not coherent (MI355X guide); weights and tables are read-only.
 // Arithmetic is conv_rows16_kernel's instruction for instruction (v_mfma_f32_16x16x32_f16, accumulators start from the bias, chunks
 // ascending, taps kx-major inside a chunk, register epilogue): results are BIT-IDENTICAL, which is the kernel's parity oracle
 // (tests/test_gpu_trunk.py) on top of the usual one.
-// LDS: two stages of [40 pieces of halo pixels | 36 pieces of weights] = 2 x 77,824 B + descriptors: one workgroup per CU.
+// Hardware facts this file relies on, each probed (tools/probes/dma_oob_probe.hip): out-of-range lanes of an LDS-DMA write zeros; M0 takes a
+// full LDS byte address; the scalar offset IS part of the range check; a buffer ATOMIC at offset 0xFFFFFFFF faults (0x80000000 does not).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -32,7 +41,7 @@
 #include "trunk.hpp"
 
 #ifndef FFP_TRUNK_DBG
-#define FFP_TRUNK_DBG 0        // 1: diagnostic build — s_memtime stamps per phase of every iteration, sums of workgroup 0 behind the queue words (FFP_TRUNK_DUMP=1 prints them)
+#define FFP_TRUNK_DBG 0        // 1: diagnostic build — s_memtime stamps per phase of every step, sums of workgroup 0 behind the queue words (FFP_TRUNK_DUMP=1 prints them)
 #endif
 #ifndef FFP_TRUNK_SKIP
 #define FFP_TRUNK_SKIP 0       // diagnostic builds: COMPILE-TIME phase-skip bits (what is left keeps the production schedule): 1 epilogue, 2 MFMA, 4 DMA, 16 fragment reads
@@ -51,15 +60,17 @@ struct TG {
   static constexpr int PIX_PIECES = 39;                       // 34 x 18 = 612 halo pixels x 64 B = 38.25 KiB -> 39 pieces of 1 KiB (12 dummy pixels)
   static constexpr int PIX = PIX_PIECES * 1024;               // one pixel stage (a 32-channel chunk of the halo tile)
   static constexpr int WB = 18 * 1024;                        // one weight stage: the fragments of one 32-channel block and chunk, [tap][M-tile][lane] x 16 B
-  static constexpr int WOFF = 3 * PIX;                        // LDS: [3 pixel stages][2 weight stages][descriptor ring, snapshot words][2 bias slots]
+  static constexpr int WOFF = 3 * PIX;                        // LDS: [3 pixel stages][2 weight stages][descriptor ring, snapshot words][layer table][2 bias slots]
   static constexpr int MISC = WOFF + 2 * WB;                  // 156,672
-  static constexpr int BIAS = MISC + 4 * 64 + 64;             // 2 x 256 B
-  static constexpr int LDS = BIAS + 2 * 256;                  // 157,504 B: one workgroup per CU
+  static constexpr int CUM = MISC + 4 * 64 + 64;              // blocks before layer l, l = 0 .. n_layers (MAXL + 1 ints)
+  static constexpr int MAXL = 511;
+  static constexpr int BIAS = CUM + (MAXL + 1) * 4;           // 2 bias slots, 1 KiB apart: an LDS-DMA piece always writes 64 lanes x 16 B (zeros beyond the 128 B)
+  static constexpr int LDS = BIAS + 2 * 1024;                 // 161,088 B: one workgroup per CU
   static constexpr int ROWB = HC * 64;                        // bytes of a halo row
 };
 
 enum : int { D_EMPTY = 0, D_KNOWN = 1, D_READY = 2, D_END = 3 };
-// descriptor slot (16 ints in LDS): 0 state, 1 queue id, 2 layer, 3 tile index, 4 first pixel of the image, 5 y0 | x0 << 16, 6 h | w << 16,
+// descriptor slot (16 ints in LDS): 0 state, 1 output block, 2 layer, 3 tile index, 4 first pixel of the image, 5 y0 | x0 << 16, 6 h | w << 16,
 // 7 tile columns | tile rows << 16 of the image (4..7 = the packed tile entry, Level::tile_table_packed)
 
 __device__ __forceinline__ unsigned rfl(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
@@ -94,69 +105,72 @@ template <bool SC1> __device__ __forceinline__ void dma16(u32x4 rs, unsigned vof
 }
 
 struct Item {            // wave-uniform description of a work item (SGPRs)
-  int layer, tile, y0, x0;
-  int NC, NT;            // 32-channel input chunks, 32-channel output blocks (1 or 2)
+  int layer, tile, nb;   // nb: the 32-channel output block
+  int y0, x0;
+  int NC;                // 32-channel input chunks = steps of the item
   int H, W;              // image size
   int px0;               // first pixel of the image in the level
 };
 
 template <bool COH>      // COH: several layers in one launch — sc1 loads / stores of activations and the done[] protocol
-__global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
+__global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
   using G = TG;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
   int* const desc = reinterpret_cast<int*>(smem + G::MISC);   // 4 slots x 16 ints
-  int* const snap = desc + 64;                                  // [iteration parity]: is the item after the current one READY? (see the main loop)
+  int* const snap = desc + 64;                                  // [iteration parity]: is the item after the ones this workgroup holds READY?
+  int* const cumtab = reinterpret_cast<int*>(smem + G::CUM);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = rfl(tid >> 6);
+  const bool loader = wave >= 4;                               // waves 4..11 stage, waves 0..3 multiply — one per SIMD (wave 0 also runs the control steps)
+  const int w8 = (wave - 4) & 7;                               // loader index 0..7
   const int pc = lane & 15, g = lane >> 4;
   typedef const __attribute__((address_space(4))) TrunkLayer* LPtr;
   const LPtr layers = reinterpret_cast<LPtr>(reinterpret_cast<unsigned long long>(a.layers));
 
   const int n_tiles = a.n_tiles_dev ? sload(a.n_tiles_dev, 0) : a.ntiles_host;
-  const unsigned total = (unsigned)n_tiles * (unsigned)a.n_layers;
+  const unsigned total = (unsigned)n_tiles * (unsigned)a.n_blocks;
   if (total == 0) return;
   constexpr unsigned OOB = 0xFFFFFFFFu;
   constexpr int AUXC = COH ? 16 : 0;                          // sc1 on activation loads / stores of a multi-layer launch
 
-  unsigned isrc[6];        // byte offset of the lane's 16 bytes of chunk 0 from the image's first pixel record (+ in_coff), or OOB
-
-  // fragment read offsets: halo rows 4 * wave + j (j = 0..5), column pc + kx, slot g
+  // fragment read offsets (compute wave w: output rows 8w..8w+7): halo rows 8 * wave + r (r = 0..9), column pc + kx, slot g
   unsigned boff[3];
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) {
     const int hx = pc + kx;
-    boff[kx] = (unsigned)(((4 * wave) * G::HC + hx) * 64 + ((g ^ ((hx >> 1) & 2)) << 4));
+    boff[kx] = (unsigned)(((8 * (wave & 3)) * G::HC + hx) * 64 + ((g ^ ((hx >> 1) & 2)) << 4));
   }
+  unsigned isrc[5];        // loader waves: byte offset of the lane's 16 bytes of chunk 0 from the image's first pixel record (+ in_coff), or OOB
 
-  // ---- control (wave 0): the queue, the tile entries and the dependency counters of the next three items, one step per chunk -------------
+  // ---- control (wave 0): the queue, the tile entries and the dependency counters of the next three items -----------------------------------------
   int ck = -1;             // sequence number (within this workgroup) of the CURRENT item (-1: none yet); slot = seq & 3
   int fk = 0, fstate = 0;  // fetcher: next sequence number to fetch; 0 idle, 1 queue id asked, 2 id known, 3 tile entry asked, 4 queue exhausted
   int f_id = 0;            // pending atomic result (lane 0)
   u32x4 f_tile = {0u, 0u, 0u, 0u};
-  int f_layer = 0, f_t = 0;
-  unsigned f_qid = 0;
-  // wave 0's own copy of the four descriptor slots (scalar registers; LDS holds what the other waves read): state, layer, tile index,
-  // tile position and grid packed as tx | ty << 8 | nx << 16 | ny << 24 — a control step reads no LDS
-  int s_st[4] = {0, 0, 0, 0}, s_ly[4] = {0, 0, 0, 0}, s_tt[4] = {0, 0, 0, 0}, s_geo[4] = {0, 0, 0, 0};
+  int f_layer = 0, f_t = 0, f_nb = 0, f_need = 0;
+  int f_ly = 0;            // layer cursor of the fetcher: queue ids only grow, so the layer of an id is found by stepping this forward
+  // wave 0's own copy of the four descriptor slots (scalar registers; LDS holds what the other waves read): state, finished blocks the item's
+  // neighbourhood must show, tile index, tile position and grid packed as tx | ty << 8 | nx << 16 | ny << 24 — a control step reads no slot from LDS
+  int s_st[4] = {0, 0, 0, 0}, s_need[4] = {0, 0, 0, 0}, s_tt[4] = {0, 0, 0, 0}, s_geo[4] = {0, 0, 0, 0};
   auto get4 = [](const int (&v)[4], int k) { return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : v[3]; };
   auto put4 = [](int (&v)[4], int k, int x) { v[0] = k == 0 ? x : v[0]; v[1] = k == 1 ? x : v[1]; v[2] = k == 2 ? x : v[2]; v[3] = k == 3 ? x : v[3]; };
   int p_base = -1;         // polls in flight: sequence number of lane group 0 (-1: none)
   unsigned p_val = 0;
-  int p_need = 0;          // per lane: the layer its polled counter must have reached
+  int p_need = 0;          // per lane: the count its polled counter must have reached
   bool p_act = false;      // per lane: it polled a counter
   const auto rs_sync = __builtin_amdgcn_make_buffer_rsrc(a.queue, 0, 64 + 4 * n_tiles, 0x00020000);          // [queue | done[]]
   const auto rs_tiles = __builtin_amdgcn_make_buffer_rsrc(const_cast<int4*>(a.tiles), 0, 16 * n_tiles, 0x00020000);
   // "nothing to ask" offset of the control step's dword / atomic operations: aligned and beyond any num_records (0xFFFFFFFF + 4 wraps in
   // a 32-bit range check; a buffer ATOMIC at that offset faulted with a memory aperture violation on gfx950, 16-byte loads do not)
   constexpr unsigned OOBA = 0x80000000u;
-  // A control step has two halves. control_issue() — at the top of an iteration — asks: the queue for the next id (at most three items ahead),
+  // A control step has two halves. control_issue() — at the top of a step — asks: the queue for the next id (at most three items ahead),
   // or the tile table for the id it got, and (multi-layer launches) the dependency counters of every fetched, not yet ready item.
-  // control_consume() — at the END of the iteration, right after the wave's full vmcnt(0) wait — reads the answers. Every request is a buffer
-  // operation issued unconditionally inside the step (an out-of-range offset where there is nothing to ask): behind exec-masked loads, or for
-  // results carried over the loop's back edge, hipcc waits for vmcnt(0) at the point of use, and that wait would also cover the epilogue's
-  // stores (1-2 us: measured 1,500 cycles per iteration with the one-step form). A last-chunk iteration (stores still in flight at its end)
-  // skips the consume; nothing new is asked until the answers have been read.
+  // control_consume() — at the END of the step, after wave 0's vmcnt(0) — reads the answers. Every request is a buffer operation issued
+  // unconditionally inside the step (an out-of-range offset where there is nothing to ask): behind exec-masked loads, or for results carried
+  // over the loop's back edge, hipcc waits for vmcnt(0) at the point of use, and that wait would also cover the epilogue's stores (1-2 us:
+  // measured 1,500 cycles per step with a one-piece form). An item's last step (stores still in flight at its end) skips the consume;
+  // nothing new is asked until the answers have been read.
   unsigned f_tile_off = OOBA;
   bool ctl_pending = false;
   auto control_issue = [&]() {
@@ -173,7 +187,7 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
       const int gi = lane >> 4, j = lane & 15;
       const int sq = ck + 1 + gi, k = sq & 3;
       const int stt = get4(s_st, k), geo = get4(s_geo, k), t = get4(s_tt, k);
-      p_need = get4(s_ly, k);
+      p_need = get4(s_need, k);
       p_act = gi < 3 && j < 9 && sq < fk && stt == D_KNOWN;
       const int dy = j / 3 - 1, dx = j - (j / 3) * 3 - 1;
       const int tx = geo & 0xFF, ty = (geo >> 8) & 0xFF, nx = (geo >> 16) & 0xFF, ny = (geo >> 24) & 0xFF;
@@ -194,21 +208,28 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
         if (lane == 0) desc[(fk & 3) * 16] = D_END;
         fstate = 4;
       } else {
-        f_qid = id;
-        f_layer = (int)(id / (unsigned)n_tiles);
-        f_t = (int)(id - (unsigned)f_layer * (unsigned)n_tiles);
+        // the layer of a queue id: ids [n_tiles * cum[l], n_tiles * cum[l + 1]) belong to layer l, (tile, block) = divmod(rest, blocks of the layer)
+        // (LDS reads are per-lane values to hipcc: without the readfirstlanes the layer cursor — and every piece of control state derived from
+        // it — counts as divergent and moves from scalar to vector registers, in all twelve waves)
+        while (id >= (unsigned)n_tiles * (unsigned)rfl(cumtab[f_ly + 1])) ++f_ly;
+        const int c0 = rfl(cumtab[f_ly]), nblk = rfl(cumtab[f_ly + 1]) - c0;
+        const unsigned r = id - (unsigned)n_tiles * (unsigned)c0;
+        f_layer = f_ly;
+        f_need = c0;
+        f_t = nblk == 2 ? (int)(r >> 1) : (int)r;
+        f_nb = nblk == 2 ? (int)(r & 1u) : 0;
         f_tile_off = (unsigned)f_t * 16u;
         fstate = 2;
       }
     } else if (fstate == 3) {
       const int e0 = rfl((int)f_tile[0]), e1 = rfl((int)f_tile[1]), e2 = rfl((int)f_tile[2]), txy = rfl((int)f_tile[3]);
       const int k = fk & 3;
-      const int state = (COH && f_layer > 0) ? D_KNOWN : D_READY;       // the first layer of a launch depends on earlier launches only
-      put4(s_st, k, state); put4(s_ly, k, f_layer); put4(s_tt, k, f_t);
+      const int state = (COH && f_need > 0) ? D_KNOWN : D_READY;        // the first layer of a launch depends on earlier launches only
+      put4(s_st, k, state); put4(s_need, k, f_need); put4(s_tt, k, f_t);
       put4(s_geo, k, ((e1 >> 16) >> 4) | (((e1 & 0xFFFF) / G::TH) << 8) | ((txy & 0xFF) << 16) | (((txy >> 16) & 0xFF) << 24));
       if (lane == 0) {
         int* d = desc + k * 16;
-        d[1] = (int)f_qid; d[2] = f_layer; d[3] = f_t; d[4] = e0; d[5] = e1; d[6] = e2; d[7] = txy;
+        d[1] = f_nb; d[2] = f_layer; d[3] = f_t; d[4] = e0; d[5] = e1; d[6] = e2; d[7] = txy;
         d[0] = state;
       }
       ++fk;
@@ -229,8 +250,8 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
       p_base = -1;
     }
   };
-  // blocking form (prologue, late dependencies): until sequence `sq` is READY or the queue has ended. Bounded: a spin that never ends
-  // would hang the device — it gives up, raises the error word and ends this workgroup's walk instead
+  // blocking form (the walk's first item, late dependencies): until sequence `sq` is READY or the queue has ended. Bounded: a spin that never
+  // ends would hang the device — it gives up, raises the error word and ends this workgroup's walk instead
   auto control_wait = [&](int sq) {
     for (int spin = 0;; ++spin) {
       const int st = get4(s_st, sq & 3);
@@ -247,121 +268,104 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
   };
 
   if (tid < 80) desc[tid] = 0;
+  for (int i = tid; i <= a.n_layers; i += 768) cumtab[i] = i < a.n_layers ? a.layers[i].cum : a.n_blocks;
   __syncthreads();
 
   // ---- item set-up: descriptor slot -> SGPRs ------------------------------------------------------------------------------------------------
   auto load_item = [&](int sq) {
     const int4 d0 = *reinterpret_cast<const int4*>(desc + (sq & 3) * 16), d1 = *reinterpret_cast<const int4*>(desc + (sq & 3) * 16 + 4);
     Item it;
-    it.layer = rfl(d0.z); it.tile = rfl(d0.w);
+    it.nb = rfl(d0.y); it.layer = rfl(d0.z); it.tile = rfl(d0.w);
     it.px0 = rfl(d1.x);
     const int yx = rfl(d1.y), hw = rfl(d1.z);
     it.y0 = yx & 0xFFFF; it.x0 = (int)((unsigned)yx >> 16);
     it.H = hw & 0xFFFF; it.W = (int)((unsigned)hw >> 16);
     it.NC = layers[it.layer].cin >> 5;
-    it.NT = layers[it.layer].cout >> 5;
     return it;
   };
-  // ---- staging. The workgroup's work is ONE STREAM OF STEPS: step = (item, 32-channel input chunk c, 32-channel output block nt), 72 MFMAs per
-  // wave. A step multiplies the chunk's halo tile (pixel stage = chunk index in the stream % 3) by one block's weight fragments (weight stage
-  // = step index % 2). While it runs, the NEXT step's weights and the pixel chunk TWO chunks ahead are requested by LDS-DMA — across items:
-  // the stream runs into the next item as soon as that item is known and its dependencies are met. A 64-channel layer takes two steps per
-  // chunk over the same pixel stage.
+  // ---- staging (loader waves 8..15). The workgroup's work is ONE STREAM OF STEPS: step q = (item, 32-channel input chunk c), 72 MFMAs per compute
+  // wave. Step q multiplies the chunk's halo tile (pixel stage q % 3) by the item's weight fragments of that chunk (weight stage q % 2). While it
+  // runs, the loaders request step q + 1's weights and the pixel chunk of step q + 2 — across items: the stream runs into the next item as soon
+  // as that item is known and its dependencies are met.
   u32x4 rs_in, rs_w, rs_b;                         // pixel source (the item `pix_item` describes), weight / bias source (the item of the weight cursor)
   int pix_item = -1;                               // sequence number of the item isrc[] / rs_in describe (-1: none)
-  int w_NC = 0;                                    // chunks of the weight cursor's layer
+  int w_soff0 = 0;                                 // weight cursor: byte offset of (block nb, chunk 0) in the layer's packed fragments
   auto setup_pix = [&](const Item& it, int seq) {
     const LPtr L = layers + it.layer;
     const int cs = L->in_cs;
     const unsigned char* inb = reinterpret_cast<const unsigned char*>(L->in) + ((long long)it.px0 * cs + L->in_coff) * 2;
     rs_in = make_rsrc(inb, 0x7FFFFFF0u);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {                    // pixel piece (wave - 1) + 7 i of the 39 (waves 1..7; wave 0 stages no pixels: see pix_pieces())
-      const int p = wave - 1 + 7 * i;
-      const int q = p * 16 + (lane >> 2);            // lane -> halo pixel q = piece * 16 + lane / 4, LDS slot position lane % 4
+    for (int i = 0; i < 5; ++i) {                    // pixel piece w8 + 8 i of the 39: lane -> halo pixel q = piece * 16 + lane / 4, LDS slot position lane % 4
+      const int p = w8 + 8 * i;
+      const int q = p * 16 + (lane >> 2);
       const int hy = (q * 3641) >> 16, hx = q - hy * G::HC;          // q / 18 for q < 640
       const int sl = (lane & 3) ^ ((hx >> 1) & 2);                   // which holds SOURCE slot (lane % 4) ^ ((hx >> 1) & 2): conflict-free fragment reads
       const int iy = it.y0 - 1 + hy, ix = it.x0 - 1 + hx;
-      const bool ok = wave > 0 && p < G::PIX_PIECES && q < G::HR * G::HC && (unsigned)iy < (unsigned)it.H && (unsigned)ix < (unsigned)it.W;
+      const bool ok = p < G::PIX_PIECES && q < G::HR * G::HC && (unsigned)iy < (unsigned)it.H && (unsigned)ix < (unsigned)it.W;
       isrc[i] = ok ? (unsigned)((iy * it.W + ix) * cs * 2 + sl * 16) : OOB;
     }
     pix_item = seq;
   };
   auto setup_w = [&](const Item& it) {
     const LPtr L = layers + it.layer;
-    rs_w = make_rsrc(L->wpk, (unsigned)(it.NT * it.NC * G::WB));
-    rs_b = make_rsrc(L->bias, (unsigned)(it.NT * 128));
-    w_NC = it.NC;
+    const int nblk = L->cout >> 5;
+    rs_w = make_rsrc(L->wpk, (unsigned)(nblk * it.NC * G::WB));
+    rs_b = make_rsrc(L->bias + it.nb * 32, 128u);
+    w_soff0 = it.nb * it.NC * G::WB;
   };
-  // one wave-piece (64 lanes x 16 B) per call. Pixel chunk c of the item isrc[] describes -> pixel stage at LDS address `st`: pieces wave + 8 i.
-  // Wave 0 stages NO pixel pieces: its vector-memory queue then holds nothing younger than its control requests and weight pieces at the end
-  // of a step, so reading the control answers (a full vmcnt(0) as far as hipcc can tell) waits for nothing that is still meant to be in flight.
+  // one wave-piece (64 lanes x 16 B) per call. Pixel chunk c of the item isrc[] describes -> pixel stage at LDS address `st`: pieces w8 + 8 i.
   auto dma_pix = [&](int c, unsigned st, int i) {
     if ((FFP_TRUNK_SKIP & 4)) return;
-    const int p = wave - 1 + 7 * i;
-    if (wave > 0 && p < G::PIX_PIECES) dma16<COH>(rs_in, isrc[i], (unsigned)(c * 64), st + (unsigned)(p << 10));
+    const int p = w8 + 8 * i;
+    if (p < G::PIX_PIECES) dma16<COH>(rs_in, isrc[i], (unsigned)(c * 64), st + (unsigned)(p << 10));
   };
-  const int pix_pieces = wave == 0 ? 0 : (wave <= 4 ? 6 : 5);           // 39 = 4 x 6 + 3 x 5
+  const int pix_pieces = w8 < 7 ? 5 : 4;           // 39 = 7 x 5 + 4
+  // weight fragments of chunk c of the weight cursor's block -> weight stage at `st`: pieces w8 + 8 j < 18; with first = true also the block's
+  // bias (128 B; loader 7's third slot) -> bias slot at `bst`
+  auto dma_w = [&](int c, unsigned st, int j, bool first, unsigned bst) {
+    if ((FFP_TRUNK_SKIP & 4)) return;
+    const int q = w8 + 8 * j;
+    if (q < 18) dma16<false>(rs_w, (unsigned)lane * 16u, (unsigned)(w_soff0 + ((c * 18 + q) << 10)), st + (unsigned)(q << 10));
+    else if (first && q == 23) dma16<false>(rs_b, lane < 8 ? (unsigned)lane * 16u : OOB, 0u, bst);
+  };
   // wait until at most `keep` of this wave's vector-memory operations are outstanding (the youngest ones: a step's pixel pieces are requested
-  // last and belong to the chunk two chunks ahead — they are NOT waited for at the end of the step that requests them)
+  // last and belong to the step after next — they are NOT waited for at the end of the step that requests them)
   auto wait_keep = [&](int keep) {
     switch (keep) {
-      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
       case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
       case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
   };
-  // weight fragments of (chunk c, block nt) of the weight cursor's layer -> weight stage at `st`: pieces wave + 8 j < 18; with first = true
-  // also the layer's bias (256 B, wave 7's third slot) -> bias slot at `bst`
-  auto dma_w = [&](int c, int nt, unsigned st, int j, bool first, unsigned bst) {
-    if ((FFP_TRUNK_SKIP & 4)) return;
-    const int q = wave + 8 * j;
-    if (q < 18) dma16<false>(rs_w, (unsigned)lane * 16u, (unsigned)(((nt * w_NC + c) * 18 + q) << 10), st + (unsigned)(q << 10));
-    else if (first && q == 23) dma16<false>(rs_b, lane < 16 ? (unsigned)lane * 16u : OOB, 0u, bst);
-  };
+  auto wait_all = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
-  // ---- arithmetic: conv_rows16_kernel's chunk for ONE 32-channel output block, always on the FRONT accumulators acc[.][0], acc[.][1]. A 64-channel
-  // layer keeps its second block in acc[.][2], acc[.][3] and swaps the two sets between steps (32 v_swap per step, ~4 % of it): ONE instance of
-  // the 72-MFMA body instead of two — with two, hipcc ran out of registers at the merge of the two paths (70 spilled, 8 of them inside the stream).
-  f32x4 acc[4][4];
-  auto init_acc = [&](const Item& it, const unsigned char* bias) {      // the bias came by DMA with the item's first weight stage: no global load at an item's start
+  // ---- arithmetic (compute waves 0..3): conv_rows16_kernel's sums for one 32-channel output block, EIGHT output rows per wave --------------------
+  f32x4 acc[8][2];
+  auto init_acc = [&](const unsigned char* bias) {      // the bias came by DMA with the item's first weight stage: no global load at an item's start
     const float* b = reinterpret_cast<const float*>(bias);
+    const float4 b0 = *reinterpret_cast<const float4*>(b + 8 * g);
+    const float4 b1 = *reinterpret_cast<const float4*>(b + 8 * g + 4);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      if (nt < it.NT) {
-        const float4 b0 = *reinterpret_cast<const float4*>(b + nt * 32 + 8 * g);
-        const float4 b1 = *reinterpret_cast<const float4*>(b + nt * 32 + 8 * g + 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc[i][nt * 2] = f32x4{b0.x, b0.y, b0.z, b0.w};
-          acc[i][nt * 2 + 1] = f32x4{b1.x, b1.y, b1.z, b1.w};
-        }
-      }
+    for (int i = 0; i < 8; ++i) {
+      acc[i][0] = f32x4{b0.x, b0.y, b0.z, b0.w};
+      acc[i][1] = f32x4{b1.x, b1.y, b1.z, b1.w};
     }
   };
-  auto swap_blocks = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int m = 0; m < 2; ++m) { const f32x4 t = acc[i][m]; acc[i][m] = acc[i][2 + m]; acc[i][2 + m] = t; }
-  };
-  auto chunk = [&](const unsigned char* sp, const unsigned char* sw, auto&& between) {
-    // Input-row fragments in EIGHT rolling slots instead of two sets of six: fragment (kx, row r) lives in slot (r + 6 kx) % 8 and is read
-    // from LDS at least one step before its first MFMA, into a slot whose previous row is dead (row r of a kx serves the steps ky = r - 3 .. r):
-    //   step 0: (1,0) (1,1) | 1: (1,2) | 2: (1,3) | 3: (1,4) (1,5) | 4: (2,0) (2,1) (2,2) | 5: (2,3) | 6: (2,4) (2,5)
-    // 16 registers fewer than the double set; the weight fragments are one step ahead (a step is 8 MFMAs: 128 cycles of cover, 256 with the partner wave).
+  // A chunk is 18 tap steps of 8 MFMAs: for kx: for row group grp (rows 4 grp .. + 3): for ky — every accumulator still meets its taps in
+  // conv_rows16's order (kx-major), so the sums are the same bits. Tap step (kx, grp, ky) multiplies input rows 4 grp + ky + i (i = 0..3) of
+  // the kx-shifted halo rows 0..9. Row fragments live in EIGHT rolling slots, slot = (10 kx + row) % 8, each read from LDS one tap step before
+  // its first use, into a slot whose previous row is dead (first uses within a kx, by t = 3 grp + ky: t0 rows 0-3, t1 row 4, t2 row 5,
+  // t3 rows 6-7, t4 row 8, t5 row 9): 10 row reads per kx for 48 MFMAs (0.21 KiB per MFMA, conv_rows16: 0.25) and the chunk's 18 weight
+  // fragments twice (once per row group; 0.25 KiB per MFMA), one tap step ahead.
+  auto chunk = [&](const unsigned char* sp, const unsigned char* sw) {
     uint4 bq[8] = {}, aq[2][2] = {};
     auto ldB1 = [&](int kx, int r) {
-      if ((FFP_TRUNK_SKIP & 16)) { asm volatile("" : "+v"(bq[(r + 6 * kx) & 7].x), "+v"(bq[(r + 6 * kx) & 7].y), "+v"(bq[(r + 6 * kx) & 7].z), "+v"(bq[(r + 6 * kx) & 7].w)); return; }
-      bq[(r + 6 * kx) & 7] = *reinterpret_cast<const uint4*>(sp + boff[kx] + r * G::ROWB);
+      if ((FFP_TRUNK_SKIP & 16)) { asm volatile("" : "+v"(bq[(10 * kx + r) & 7].x), "+v"(bq[(10 * kx + r) & 7].y), "+v"(bq[(10 * kx + r) & 7].z), "+v"(bq[(10 * kx + r) & 7].w)); return; }
+      bq[(10 * kx + r) & 7] = *reinterpret_cast<const uint4*>(sp + boff[kx] + r * G::ROWB);
     };
-    auto ldA = [&](int s, int q) {
-      const int tap = (s % 3) * 3 + s / 3;
+    auto ldA = [&](int T, int q) {                 // tap step T = 6 kx + 3 grp + ky: the packed tap index is ky * 3 + kx
+      const int kx = T / 6, ky = T % 3, tap = ky * 3 + kx;
       if ((FFP_TRUNK_SKIP & 16)) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) asm volatile("" : "+v"(aq[q][m].x), "+v"(aq[q][m].y), "+v"(aq[q][m].z), "+v"(aq[q][m].w));
@@ -371,29 +375,27 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
       for (int m = 0; m < 2; ++m) aq[q][m] = *reinterpret_cast<const uint4*>(sw + lane * 16 + ((tap * 2 + m) << 10));
     };
 #pragma unroll
-    for (int r = 0; r < 6; ++r) ldB1(0, r);
+    for (int r = 0; r < 4; ++r) ldB1(0, r);
     ldA(0, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 9; ++s) {
-      const int kx = s / 3, ky = s - 3 * kx;
-      if (s + 1 < 9) ldA(s + 1, (s + 1) & 1);
-      if (s == 0) { ldB1(1, 0); ldB1(1, 1); }
-      if (s == 1) ldB1(1, 2);
-      if (s == 2) ldB1(1, 3);
-      if (s == 3) { ldB1(1, 4); ldB1(1, 5); }
-      if (s == 4) { ldB1(2, 0); ldB1(2, 1); ldB1(2, 2); }
-      if (s == 5) ldB1(2, 3);
-      if (s == 6) { ldB1(2, 4); ldB1(2, 5); }
-      between(s);
+    for (int T = 0; T < 18; ++T) {
+      const int kx = T / 6, t = T % 6, grp = t / 3, ky = t % 3;
+      if (T + 1 < 18) ldA(T + 1, (T + 1) & 1);
+      if (t == 0) ldB1(kx, 4);
+      if (t == 1) ldB1(kx, 5);
+      if (t == 2) { ldB1(kx, 6); ldB1(kx, 7); }
+      if (t == 3) ldB1(kx, 8);
+      if (t == 4) ldB1(kx, 9);
+      if (t == 5 && kx < 2) { ldB1(kx + 1, 0); ldB1(kx + 1, 1); ldB1(kx + 1, 2); ldB1(kx + 1, 3); }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           if ((FFP_TRUNK_SKIP & 2)) continue;
           union { uint4 u; f16x8 h; } ua, ub;
-          ua.u = aq[s & 1][m]; ub.u = bq[(i + ky + 6 * kx) & 7];
-          acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ua.h, ub.h, acc[i][m], 0, 0, 0);
+          ua.u = aq[T & 1][m]; ub.u = bq[(10 * kx + 4 * grp + ky + i) & 7];
+          acc[4 * grp + i][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ua.h, ub.h, acc[4 * grp + i][m], 0, 0, 0);
         }
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
@@ -404,7 +406,7 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
     }
   };
 
-  // ---- epilogue: lane (pc, g) holds channels 32 nt + 8 g .. + 7 of pixel (row 4 * wave + i, column pc); 4 NT stores per wave -----------------
+  // ---- epilogue: lane (pc, g) holds channels 32 nb + 8 g .. + 7 of pixel (row 8 * wave + i, column pc); 8 stores per compute wave ---------------
   struct Epi {             // the epilogue's layer parameters (scalar loads issued BEFORE the last step's MFMAs: their latency is off the item's tail)
     const unsigned char *ob, *r1b, *r2b;
     int act, o_cs, r1_cs, r2_cs;
@@ -434,168 +436,179 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
     };
     const auto rs_o = mk(e.ob), rs_r1 = mk(e.r1b), rs_r2 = mk(e.r2b);
     const int ox = it.x0 + pc;
+    const int ch0 = it.nb * 32 + 8 * g;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      if (nt >= it.NT) break;
-      // one 32-channel block at a time: hipcc otherwise hoists the residual loads of all eight (row, block) pairs (64 registers)
-      __builtin_amdgcn_sched_barrier(0);
-      const int ch0 = nt * 32 + 8 * g;
+    for (int i = 0; i < 8; ++i) {
+      if (i == 4) __builtin_amdgcn_sched_barrier(0);             // four rows at a time: hipcc otherwise hoists every row's residual loads (64 registers)
+      const int oy = it.y0 + 8 * (wave & 3) + i;
+      const bool ok = oy < it.H && ox < it.W;
+      const unsigned rel = (unsigned)(oy * it.W + ox);
+      u32x4 r1v = {0u, 0u, 0u, 0u}, r2v = r1v;
+      if (has1) r1v = __builtin_amdgcn_raw_buffer_load_b128(rs_r1, ok ? (rel * r1_cs + ch0) * 2 : OOB, 0, AUXC);
+      if (has2) r2v = __builtin_amdgcn_raw_buffer_load_b128(rs_r2, ok ? (rel * r2_cs + ch0) * 2 : OOB, 0, AUXC);
+      float v[8];
+      v[0] = acc[i][0][0]; v[1] = acc[i][0][1]; v[2] = acc[i][0][2]; v[3] = acc[i][0][3];
+      v[4] = acc[i][1][0]; v[5] = acc[i][1][1]; v[6] = acc[i][1][2]; v[7] = acc[i][1][3];
+      if (act == ACT_LRELU) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int oy = it.y0 + 4 * wave + i;
-        const bool ok = oy < it.H && ox < it.W;
-        const unsigned rel = (unsigned)(oy * it.W + ox);
-        u32x4 r1v = {0u, 0u, 0u, 0u}, r2v = r1v;
-        if (has1) r1v = __builtin_amdgcn_raw_buffer_load_b128(rs_r1, ok ? (rel * r1_cs + ch0) * 2 : OOB, 0, AUXC);
-        if (has2) r2v = __builtin_amdgcn_raw_buffer_load_b128(rs_r2, ok ? (rel * r2_cs + ch0) * 2 : OOB, 0, AUXC);
-        float v[8];
-        // where block nt's sums are after the item's last step: a 64-channel layer ends on block 1, so block 0 sits in the back set
-        const f32x4 a0 = it.NT == 2 ? acc[i][2 - 2 * nt] : acc[i][0], a1 = it.NT == 2 ? acc[i][3 - 2 * nt] : acc[i][1];
-        v[0] = a0[0]; v[1] = a0[1]; v[2] = a0[2]; v[3] = a0[3];
-        v[4] = a1[0]; v[5] = a1[1]; v[6] = a1[2]; v[7] = a1[3];
-        if (act == ACT_LRELU) {
+        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], v[q] * 0.2f);
+      } else if (act == ACT_SILU) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], v[q] * 0.2f);
-        } else if (act == ACT_SILU) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = apply_act(v[q], ACT_SILU);
-        }
-        if (has1) {
-          const _Float16* r = reinterpret_cast<const _Float16*>(&r1v);
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = v[q] * s1 + (float)r[q];
-        }
-        if (has2) {
-          const _Float16* r = reinterpret_cast<const _Float16*>(&r2v);
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = v[q] * s2 + (float)r[q];
-        }
-        union { u32x4 u; _Float16 h[8]; } ov;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) ov.h[q] = (_Float16)v[q];
-        __builtin_amdgcn_raw_buffer_store_b128(ov.u, rs_o, ok ? (rel * o_cs + ch0) * 2 : OOB, 0, AUXC);
+        for (int q = 0; q < 8; ++q) v[q] = apply_act(v[q], ACT_SILU);
       }
+      if (has1) {
+        const _Float16* r = reinterpret_cast<const _Float16*>(&r1v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = v[q] * s1 + (float)r[q];
+      }
+      if (has2) {
+        const _Float16* r = reinterpret_cast<const _Float16*>(&r2v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = v[q] * s2 + (float)r[q];
+      }
+      union { u32x4 u; _Float16 h[8]; } ov;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ov.h[q] = (_Float16)v[q];
+      __builtin_amdgcn_raw_buffer_store_b128(ov.u, rs_o, ok ? (rel * o_cs + ch0) * 2 : OOB, 0, AUXC);
     }
   };
-  auto publish = [&](int tile, int layer) {        // every wave has drained its stores and the workgroup has met at a barrier since
+  auto publish = [&](int tile) {                   // every compute wave has drained its stores and the workgroup has met at a barrier since
     if ((FFP_TRUNK_SKIP & 64)) return;
-    if (COH && tid == 0) __hip_atomic_store(a.done + tile, (unsigned)(layer + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (COH && tid == 0) __hip_atomic_fetch_add(a.done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  auto wait_all = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
-  // ---- the walk --------------------------------------------------------------------------------------------------------------------------------
-  if (wave == 0) control_wait(0);
-  __syncthreads();
+  // ---- the walk: ONE body, instantiated per role — a compute wave's loop then carries no staging state and a loader's loop no accumulators (with
+  // one loop for both roles hipcc spilled 65-190 registers at the 168 a 12-wave workgroup leaves each wave). Both instances take the same
+  // decisions from the same words in LDS and their own copies of the wave-uniform cursors: they meet at the same barriers. ------------------------------
+  auto walk = [&](auto role_tag) {
+  constexpr bool LD = decltype(role_tag)::value;
   if (rfl(desc[0]) != D_READY) return;
   ck = 0;
   Item cur = load_item(0), nxt = cur;
   bool have_nxt = false;
-  int c = 0, nt = 0;
-  unsigned sidx = 0;       // step index in the stream: weight stage = sidx & 1
-  unsigned pq = 0;         // chunk index in the stream of the chunk being multiplied: pixel stage = pq % 3
-  unsigned pix_next = 0;   // chunk index in the stream of the next pixel chunk to request (pix_next > pq: this chunk is in LDS or on its way)
-  unsigned pix_base = 0;   // chunk index in the stream of the current item's chunk 0
+  int c = 0;               // chunk of the current item = its step
+  unsigned q = 0;          // step index in the stream: weight stage q & 1, pixel stage q % 3
+  unsigned q0 = 0;         // stream index of the current item's chunk 0
+  unsigned pix_next = 0;   // stream index of the next pixel chunk to request (pix_next > q: this step's chunk is in LDS or on its way)
   bool w_have = false;     // this step's weights have been requested (in the previous step)
-  int pub_tile = -1, pub_layer = 0;
+  int pub_tile = -1;
   auto pstage = [&](unsigned n) { return lds0 + (n % 3u) * G::PIX; };
-  // which (item, chunk) is chunk index n of the stream? 0: the current item, 1: the next one, -1: not known yet
-  auto chunk_of = [&](unsigned n, int& cc) {
-    const int o = (int)(n - pix_base);
+  // which (item, chunk) is step n of the stream? 0: the current item, 1: the next one, -1: not known yet
+  auto step_of = [&](unsigned n, int& cc) {
+    const int o = (int)(n - q0);
     if (o < cur.NC) { cc = o; return 0; }
     if (have_nxt && o - cur.NC < nxt.NC) { cc = o - cur.NC; return 1; }
     cc = 0;
     return -1;
   };
 #if FFP_TRUNK_DBG
-  unsigned long long tsum[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();      // control, epilogue parameters, step, epilogue + next-item set-up, wait, barrier, synchronous staging
+  unsigned long long tsum[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();      // top + control, set-up, step (MFMAs / DMA issue), epilogue + next item, wait, barrier, synchronous staging
   unsigned n_iter = 0, n_slow = 0;
 #define TSTAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsum[k] += t_ - tprev; tprev = t_; }
-#define TDUMP() if (blockIdx.x == 0 && lane == 0 && wave < 2) { unsigned* o = a.queue + 2 + wave * 7; for (int k_ = 0; k_ < 7; ++k_) o[k_] = (unsigned)(tsum[k_] / (n_iter ? n_iter : 1)); \
-                  if (wave == 1) { o[6] = n_iter | (n_slow << 16); } }
+#define TDUMP() if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) { unsigned* o = a.queue + 2 + (wave >> 2) * 7; for (int k_ = 0; k_ < 7; ++k_) o[k_] = (unsigned)(tsum[k_] / (n_iter ? n_iter : 1)); \
+                  if (wave == 4) { o[6] = n_iter | (n_slow << 16); } }
 #else
 #define TSTAMP(k)
 #define TDUMP()
 #endif
   for (unsigned itn = 0;; ++itn) {
-    // ---- operands of this step not requested yet (the walk's first step, after a late dependency, after a gap in the look-ahead): request them
-    // now — and as much of the look-ahead as is known — and wait. Every wave takes the same branch (the cursors are wave-uniform).
-    if (pix_next <= pq || !w_have) {
-      while (pix_next <= pq + 2) {
+    // ---- operands of this step not requested yet (the walk's first step, after a late dependency, after a gap in the look-ahead): the loaders
+    // request them now — and as much of the look-ahead as is known — and wait. Every wave takes the same branch (the cursors are wave-uniform).
+    if (pix_next <= q || !w_have) {
+      while (pix_next <= q + 2) {
         int cc;
-        const int which = chunk_of(pix_next, cc);
+        const int which = step_of(pix_next, cc);
         if (which < 0) break;
-        const int seq = ck + which;
-        if (pix_item != seq) setup_pix(which ? nxt : cur, seq);
+        if constexpr (LD) {
+          const int seq = ck + which;
+          if (pix_item != seq) setup_pix(which ? nxt : cur, seq);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) dma_pix(cc, pstage(pix_next), i);
+          for (int i = 0; i < 5; ++i) dma_pix(cc, pstage(pix_next), i);
+        }
         ++pix_next;
       }
       if (!w_have) {
-        setup_w(cur);
+        if constexpr (LD) {
+          setup_w(cur);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) dma_w(c, nt, lds0 + G::WOFF + (sidx & 1u) * G::WB, j, c == 0 && nt == 0, lds0 + G::BIAS + (unsigned)(ck & 1) * 256u);
+          for (int j = 0; j < 3; ++j) dma_w(c, lds0 + G::WOFF + (q & 1u) * G::WB, j, c == 0, lds0 + G::BIAS + (unsigned)(ck & 1) * 1024u);
+        }
         w_have = true;
       }
       wait_all();
       __syncthreads();
-      if (c == 0 && nt == 0) init_acc(cur, smem + G::BIAS + (ck & 1) * 256);
+      if (c == 0 && !LD) init_acc(smem + G::BIAS + (ck & 1) * 1024);
 #if FFP_TRUNK_DBG
       ++n_slow;
 #endif
       TSTAMP(6)
     }
-    const bool last = c == cur.NC - 1 && nt == cur.NT - 1;       // the item's last step
-    const bool nxt_known = rfl(snap[itn & 1u]) != 0;             // is the item after this one READY? (wave 0's snapshot of the PREVIOUS iteration: uniform)
-    if (wave == 0) control_issue();
+    const bool last = c == cur.NC - 1;                           // the item's last step
+    const bool nxt_known = rfl(snap[itn & 1u]) != 0;             // is the item after the ones held READY? (wave 0's snapshot of the PREVIOUS iteration: uniform)
+    if (!LD && wave == 0) control_issue();
     TSTAMP(0)
-    Epi ep = {};
-    if (last) ep = load_epi(cur);
-    TSTAMP(1)
-    // ---- what is requested while this step multiplies: the next step's weights (this item's, or the next item's first) ...
-    int wc = c, wnt = nt + 1, wwhich = 0;
-    if (wnt == cur.NT) { wnt = 0; ++wc; }
+    // ---- what is requested while this step multiplies: the next step's weights (this item's next chunk, or the next item's first) and ONE
+    // pixel chunk, up to two steps ahead
+    int wc = c + 1, wwhich = 0;
     if (wc == cur.NC) { wc = 0; wwhich = have_nxt ? 1 : -1; }
-    const bool w_first = wwhich == 1;                            // the next item's first step: its bias rides along
-    if (wwhich == 1) setup_w(nxt);                               // (scalar loads; this item's weight cursor has no further use for rs_w)
-    const unsigned wst = lds0 + G::WOFF + ((sidx + 1u) & 1u) * G::WB, bst = lds0 + G::BIAS + (unsigned)((ck + 1) & 1) * 256u;
-    // ... and ONE pixel chunk, up to two chunks ahead of the one being multiplied (only in a chunk's first step)
     int pcc = 0, pwhich = -1;
-    if (nt == 0 && pix_next <= pq + 2) pwhich = chunk_of(pix_next, pcc);
-    if (pwhich >= 0 && pix_item != ck + pwhich) setup_pix(pwhich ? nxt : cur, ck + pwhich);
-    const unsigned p_idx = pix_next, pst = pstage(pix_next);
-    auto between = [&](int step) {                               // MFMA step 0..8 of this step: weights first (needed one step from now), then the pixel pieces
-      if (step < 3) { if (wwhich >= 0) dma_w(wc, wnt, wst, step, w_first, bst); }
-      else { if (pwhich >= 0) dma_pix(pcc, pst, step - 3); }            // steps 3..8: six slots
-    };
-    const unsigned char* sp = smem + (pq % 3u) * G::PIX;
-    const unsigned char* sw = smem + G::WOFF + (sidx & 1u) * G::WB;
-    chunk(sp, sw, between);
-    if (cur.NT == 2 && !last) swap_blocks();                    // the other block's sums to the front for the next step (after the last step: block 1 in front)
+    if (pix_next <= q + 2) pwhich = step_of(pix_next, pcc);
+    const unsigned p_idx = pix_next;
+    int npix = 0;
+    if constexpr (LD) {
+      if (wwhich == 1) setup_w(nxt);
+      if (pwhich >= 0 && pix_item != ck + pwhich) setup_pix(pwhich ? nxt : cur, ck + pwhich);
+      TSTAMP(1)
+      const unsigned wst = lds0 + G::WOFF + ((q + 1u) & 1u) * G::WB, bst = lds0 + G::BIAS + (unsigned)((ck + 1) & 1) * 1024u;
+      if (wwhich >= 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dma_w(wc, wst, j, wwhich == 1, bst);
+      }
+      if (pwhich >= 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dma_pix(pcc, pstage(p_idx), i);
+        // the pixel pieces are the youngest requests and belong to the step after next: they stay in flight over this step's end — unless the
+        // look-ahead had a gap and the chunk requested here is the NEXT step's
+        if (p_idx == q + 2u) npix = pix_pieces;
+      }
+      TSTAMP(2)
+    } else {
+      Epi ep = {};
+      if (last) ep = load_epi(cur);
+      TSTAMP(1)
+      chunk(smem + (q % 3u) * G::PIX, smem + G::WOFF + (q & 1u) * G::WB);
+      TSTAMP(2)
+      if (last) {
+        if (!(FFP_TRUNK_SKIP & 1)) {
+          epilogue(cur, ep);
+        } else {                                   // diagnostic build: keep the sums alive without the epilogue
+#pragma unroll
+          for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(acc[i][0]), "v"(acc[i][1]));
+        }
+      }
+    }
     if (pwhich >= 0) ++pix_next;
     const bool w_next_have = wwhich >= 0;
-    TSTAMP(2)
-    if (last) {
-      if (!(FFP_TRUNK_SKIP & 1)) epilogue(cur, ep);
-    }
     if (!have_nxt && nxt_known) {                  // the next item's descriptor (LDS reads + scalar loads: they overlap the wait below)
       nxt = load_item(ck + 1);
       have_nxt = true;
     }
     TSTAMP(3)
-    // the end of the step: the next step's weights (requested first) must be in LDS; this step's pixel pieces (requested after them, for the chunk
-    // two chunks ahead) and the epilogue's 4 NT stores (younger still) stay in flight
-    // (only when that chunk really is two ahead: after a gap in the look-ahead the chunk requested here is the NEXT one and must land now)
-    const int npix = (pwhich >= 0 && p_idx == pq + 2u) ? pix_pieces : 0;
-    if (last) {
-      wait_keep(npix + 4 * cur.NT);
-    } else {
+    // ---- the end of the step. Loaders: the next step's weights (requested first) must be in LDS, this step's pixel pieces stay in flight.
+    // Compute waves: on every step but an item's last, everything they have asked for is back — the previous item's stores (what the deferred
+    // publish below relies on) and wave 0's control requests; an item's last step leaves its four stores in flight.
+    if constexpr (LD) {
       wait_keep(npix);
-      if (wave == 0) control_consume();            // wave 0: npix = 0, everything it has asked for is back
+    } else {
+      if (!last) {
+        wait_all();
+        if (wave == 0) control_consume();
+      }
     }
     const bool switching = last && w_next_have;    // the stream runs on into the next item
-    if (tid == 0) {                                // is the item after the ones this workgroup will hold in the next iteration READY?
-      const int nseq = switching ? ck + 2 : ck + 1;
-      snap[(itn + 1u) & 1u] = get4(s_st, nseq & 3) == D_READY ? 1 : 0;
+    if (!LD && tid == 0) {                         // is the item after the ones this workgroup will hold in the next iteration READY (and not held yet)?
+      const bool will_hold_next = have_nxt && !switching;
+      snap[(itn + 1u) & 1u] = !will_hold_next && get4(s_st, (switching ? ck + 2 : ck + 1) & 3) == D_READY ? 1 : 0;
     }
     TSTAMP(4)
     __syncthreads();
@@ -604,48 +617,43 @@ __global__ void __launch_bounds__(512, 2) conv_trunk_kernel(const TrunkArgs a) {
     ++n_iter;
 #endif
     if (pub_tile >= 0 && !last) {                  // the previous item: its stores were drained by this (non-final) step's full wait
-      publish(pub_tile, pub_layer);
+      if (!LD) publish(pub_tile);
       pub_tile = -1;
     }
-    ++sidx;
+    ++q;
     w_have = w_next_have;
-    if (!last) {
-      if (++nt == cur.NT) { nt = 0; ++c; ++pq; }
-      continue;
-    }
+    if (!last) { ++c; continue; }
     // ---- the item is finished
-    if (tid == 0) desc[(ck & 3) * 16] = D_EMPTY;   // its slot: sequence ck + 4 will be fetched into it
-    if (wave == 0) put4(s_st, ck & 3, D_EMPTY);
-    ++pq;
-    pix_base += (unsigned)cur.NC;
-    nt = 0; c = 0;
+    if (!LD && tid == 0) desc[(ck & 3) * 16] = D_EMPTY;   // its slot: sequence ck + 4 will be fetched into it
+    if (!LD && wave == 0) put4(s_st, ck & 3, D_EMPTY);
+    q0 += (unsigned)cur.NC;
+    c = 0;
     if (switching) {
-      if (pub_tile >= 0) {                         // (an item of ONE step cannot occur: cin >= 64; kept for safety) drain and publish the older one now
-        wait_all();
-        __syncthreads();
-        publish(pub_tile, pub_layer);
-      }
-      pub_tile = cur.tile; pub_layer = cur.layer;
+      pub_tile = cur.tile;
       cur = nxt; have_nxt = false; ++ck;
-      init_acc(cur, smem + G::BIAS + (ck & 1) * 256);
+      if (!LD) init_acc(smem + G::BIAS + (ck & 1) * 1024);
       continue;
     }
     // the next item is not known or not ready (or there is none): finish this one for good, then wait for it
     wait_all();
     __syncthreads();
-    if (pub_tile >= 0) { publish(pub_tile, pub_layer); pub_tile = -1; }
-    publish(cur.tile, cur.layer);
-    if (wave == 0) control_wait(ck + 1);
+    if (!LD) publish(cur.tile);
+    if (!LD && wave == 0) control_wait(ck + 1);
     __syncthreads();
     if (rfl(desc[((ck + 1) & 3) * 16]) != D_READY) { TDUMP() return; }
     ++ck;
     cur = load_item(ck);
     have_nxt = false;
-    pix_next = pq;                                 // nothing of the new item has been requested: the top of the loop does it and waits
+    pix_next = q;                                  // nothing of the new item has been requested: the top of the loop does it and waits
     w_have = false;
-    if (tid == 0) { snap[0] = 0; snap[1] = 0; }
+    if (!LD && tid == 0) { snap[0] = 0; snap[1] = 0; }
     __syncthreads();
   }
+  };
+  if (wave == 0) control_wait(0);
+  __syncthreads();
+  if (loader) walk(std::true_type{});
+  else walk(std::false_type{});
 }
 
 }  // namespace
@@ -674,9 +682,10 @@ bool conv_trunk_layer_ok(const ConvOp& op) {
 }
 
 TrunkPlan::TrunkPlan(const std::vector<ConvOp>& ops) {
-  FFP_CHECK(!ops.empty(), FFP_ERR_ARG, "trunk: no layers");
+  FFP_CHECK(!ops.empty() && (int)ops.size() <= TG::MAXL, FFP_ERR_ARG, "trunk: %d layers (1..%d)", (int)ops.size(), TG::MAXL);
   lvl = ops[0].out.lvl;
   std::vector<TrunkLayer> h(ops.size());
+  int cum = 0;
   for (size_t i = 0; i < ops.size(); ++i) {
     const ConvOp& op = ops[i];
     FFP_CHECK(conv_trunk_layer_ok(op) && op.out.lvl == lvl, FFP_ERR_ARG, "trunk: layer %s cannot run in the fused launch", op.pc->name.c_str());
@@ -688,8 +697,11 @@ TrunkPlan::TrunkPlan(const std::vector<ConvOp>& ops) {
     L.out_cs = op.out.cs; L.out_coff = op.out.coff; L.cout = op.pc->cout;
     L.r1_cs = op.res1.cs; L.r1_coff = op.res1.coff; L.r2_cs = op.res2.cs; L.r2_coff = op.res2.coff;
     L.s1 = op.s1; L.s2 = op.s2; L.act = op.act;
+    L.cum = cum;
+    cum += op.pc->cout / 32;
   }
   n_layers = (int)ops.size();
+  n_blocks = cum;
   d_layers.alloc(sizeof(TrunkLayer) * h.size());
   FFP_HIP(hipMemcpy(d_layers.p, h.data(), sizeof(TrunkLayer) * h.size(), hipMemcpyHostToDevice));
 }
@@ -703,6 +715,7 @@ void TrunkPlan::launch(hipStream_t st, int dbg) {
   a.ntiles_host = n_tiles;
   a.layers = d_layers.as<TrunkLayer>();
   a.n_layers = n_layers;
+  a.n_blocks = n_blocks;
   // [queue head, error word, padding to 64 B | done[tiles]]: zeroed before EVERY launch (a memset node under graph replay)
   const size_t need = 64 + sizeof(unsigned) * (size_t)n_tiles;
   const size_t nb = (need + 63) / 64 * 64;
@@ -710,20 +723,19 @@ void TrunkPlan::launch(hipStream_t st, int dbg) {
   FFP_HIP(hipMemsetAsync(sync.p, 0, nb, st));
   a.queue = sync.as<unsigned>();
   a.done = sync.as<unsigned>() + 16;
-  static const int env_dbg = [] { const char* e = getenv("FFP_TRUNK_DBGMASK"); return e ? atoi(e) : 0; }();      // diagnostic builds only (FFP_TRUNK_DBG)
-  a.dbg = dbg | env_dbg;
+  a.dbg = dbg;
   static const bool dump = [] { const char* e = getenv("FFP_TRUNK_DUMP"); return e && e[0] == '1'; }();
   // one workgroup per CU; capacity-mode levels launch for the capacity (workgroups beyond the batch's items find the queue empty)
-  const long long items = (long long)n_tiles * n_layers;
+  const long long items = (long long)n_tiles * n_blocks;
   const unsigned grid = (unsigned)std::min<long long>(256, items);
-  if (n_layers > 1) hipLaunchKernelGGL(conv_trunk_kernel<true>, dim3(grid), dim3(512), G::LDS, st, a);
-  else hipLaunchKernelGGL(conv_trunk_kernel<false>, dim3(grid), dim3(512), G::LDS, st, a);
+  if (n_layers > 1) hipLaunchKernelGGL(conv_trunk_kernel<true>, dim3(grid), dim3(768), G::LDS, st, a);
+  else hipLaunchKernelGGL(conv_trunk_kernel<false>, dim3(grid), dim3(768), G::LDS, st, a);
   FFP_HIP(hipGetLastError());
   if (dump) {                                          // diagnostic: the queue head, the error word and the debug words behind them
     unsigned h[16];
     FFP_HIP(hipMemcpyAsync(h, sync.p, sizeof(h), hipMemcpyDeviceToHost, st));
     FFP_HIP(hipStreamSynchronize(st));
-    fprintf(stderr, "trunk launch: tiles %d layers %d grid %u | head %u err %u | per iteration, wave 0 then wave 1: control, next-item set-up, chunk, epilogue, wait, barrier, slow path (per iteration); last word: iterations | slow paths << 16 |", n_tiles, n_layers, grid, h[0], h[1]);
+    fprintf(stderr, "trunk launch: tiles %d layers %d blocks %d grid %u | head %u err %u | cycles per step, compute wave 0 then loader wave 4: top + control, set-up, step, epilogue + next item, wait, barrier, synchronous staging; last word: steps | synchronous stagings << 16 |", n_tiles, n_layers, n_blocks, grid, h[0], h[1]);
     for (int i = 2; i < 16; ++i) fprintf(stderr, " %u", h[i]);
     fprintf(stderr, "\n");
   }

@@ -16,18 +16,20 @@ struct TrunkLayer {          // one conv of the run (device table, read through 
   int out_cs, out_coff, cout;
   int r1_cs, r1_coff, r2_cs, r2_coff;
   float s1, s2;
-  int act, pad_;
+  int act;
+  int cum;                   // 32-channel output blocks of all earlier layers of the run (an item = one block of one tile: queue ids, dependency counts)
 };
 
 struct TrunkArgs {
   const TrunkLayer* layers;
   int n_layers;
+  int n_blocks;              // blocks of all layers: items = tiles x n_blocks
   int ntiles_host;
   const int* n_tiles_dev;    // capacity-mode levels: the batch's tile count (see ConvArgs)
   const int4* tiles;         // Level::tile_table_packed(32): {first pixel of the image, y0 | x0 << 16, h | w << 16, tile columns | rows << 16} per 32 x 16 tile,
                              // the tiles of an image row-major and consecutive
   unsigned* queue;           // [0] next item, [1] error word (a dependency wait that gave up)
-  unsigned* done;            // [tile] layers completed
+  unsigned* done;            // [tile] finished (layer, block) items of the tile
   int dbg;
 };
 
@@ -37,7 +39,7 @@ struct TrunkPlan {
   void launch(hipStream_t st, int dbg = 0);
   unsigned errors(hipStream_t st);      // dependency waits that gave up during the launches so far (0 always, unless the device is wedged)
   Level* lvl = nullptr;
-  int n_layers = 0;
+  int n_layers = 0, n_blocks = 0;
   DevBuf d_layers, sync;
 };
 

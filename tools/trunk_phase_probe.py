@@ -6,7 +6,7 @@ import ffp_amd  # noqa: F401
 from ffp_amd import _lib
 for n, hw, cin, cout in ((1024, 32, 128, 32), (1024, 32, 64, 32), (1024, 32, 192, 64), (256, 32, 128, 32)):
     row = []
-    for m in (0, 1, 2, 4, 16, 6, 7, 23, 20, 22):
+    for m in (0,):
         us = min(_lib.op_conv2d_time(n, hw, hw, cin, cout, 3, 1, False, _lib.PREC_F16, 20, m, 25) for _ in range(2))
         row.append(f"{m}:{us:.1f}")
     print(f"images={n} {hw}x{hw} {cin}->{cout}: " + " ".join(row), flush=True)
