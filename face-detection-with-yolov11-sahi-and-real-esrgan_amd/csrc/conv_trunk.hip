@@ -110,6 +110,7 @@ struct Item {            // wave-uniform description of a work item (SGPRs)
   int NC;                // 32-channel input chunks = steps of the item
   int H, W;              // image size
   int px0;               // first pixel of the image in the level
+  int xchg;              // the layer has no residual inputs: its finished tile can go to the loaders through LDS (see the walk)
 };
 
 template <bool COH>      // COH: several layers in one launch — sc1 loads / stores of activations and the done[] protocol
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
     const int hx = pc + kx;
     boff[kx] = (unsigned)(((8 * (wave & 3)) * G::HC + hx) * 64 + ((g ^ ((hx >> 1) & 2)) << 4));
   }
-  unsigned isrc[5];        // loader waves: byte offset of the lane's 16 bytes of chunk 0 from the image's first pixel record (+ in_coff), or OOB
+  unsigned isrc[6];        // loader waves 1..7: byte offset of the lane's 16 bytes of chunk 0 from the image's first pixel record (+ in_coff), or OOB
 
   // ---- control (wave 0): the queue, the tile entries and the dependency counters of the next three items -----------------------------------------
   int ck = -1;             // sequence number (within this workgroup) of the CURRENT item (-1: none yet); slot = seq & 3
@@ -281,6 +282,7 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
     it.y0 = yx & 0xFFFF; it.x0 = (int)((unsigned)yx >> 16);
     it.H = hw & 0xFFFF; it.W = (int)((unsigned)hw >> 16);
     it.NC = layers[it.layer].cin >> 5;
+    it.xchg = (layers[it.layer].res1 == nullptr && layers[it.layer].res2 == nullptr) ? 1 : 0;
     return it;
   };
   // ---- staging (loader waves 8..15). The workgroup's work is ONE STREAM OF STEPS: step q = (item, 32-channel input chunk c), 72 MFMAs per compute
@@ -296,13 +298,13 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
     const unsigned char* inb = reinterpret_cast<const unsigned char*>(L->in) + ((long long)it.px0 * cs + L->in_coff) * 2;
     rs_in = make_rsrc(inb, 0x7FFFFFF0u);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {                    // pixel piece w8 + 8 i of the 39: lane -> halo pixel q = piece * 16 + lane / 4, LDS slot position lane % 4
-      const int p = w8 + 8 * i;
-      const int q = p * 16 + (lane >> 2);
+    for (int i = 0; i < 6; ++i) {                    // pixel piece (w8 - 1) + 7 i of the 39 (loaders 1..7; loader 0 runs the control steps instead: see dma_pix)
+      const int p = w8 - 1 + 7 * i;
+      const int q = p * 16 + (lane >> 2);            // lane -> halo pixel q = piece * 16 + lane / 4, LDS slot position lane % 4
       const int hy = (q * 3641) >> 16, hx = q - hy * G::HC;          // q / 18 for q < 640
       const int sl = (lane & 3) ^ ((hx >> 1) & 2);                   // which holds SOURCE slot (lane % 4) ^ ((hx >> 1) & 2): conflict-free fragment reads
       const int iy = it.y0 - 1 + hy, ix = it.x0 - 1 + hx;
-      const bool ok = p < G::PIX_PIECES && q < G::HR * G::HC && (unsigned)iy < (unsigned)it.H && (unsigned)ix < (unsigned)it.W;
+      const bool ok = w8 > 0 && p < G::PIX_PIECES && q < G::HR * G::HC && (unsigned)iy < (unsigned)it.H && (unsigned)ix < (unsigned)it.W;
       isrc[i] = ok ? (unsigned)((iy * it.W + ix) * cs * 2 + sl * 16) : OOB;
     }
     pix_item = seq;
@@ -314,13 +316,15 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
     rs_b = make_rsrc(L->bias + it.nb * 32, 128u);
     w_soff0 = it.nb * it.NC * G::WB;
   };
-  // one wave-piece (64 lanes x 16 B) per call. Pixel chunk c of the item isrc[] describes -> pixel stage at LDS address `st`: pieces w8 + 8 i.
+  // one wave-piece (64 lanes x 16 B) per call. Pixel chunk c of the item isrc[] describes -> pixel stage at LDS address `st`: pieces (w8 - 1) + 7 i.
+  // Loader 0 stages NO pixel pieces: it runs the control steps, and at the end of a step its vector-memory queue must hold nothing that is meant
+  // to stay in flight — reading the control answers is a vmcnt(0) as far as hipcc can tell.
   auto dma_pix = [&](int c, unsigned st, int i) {
     if ((FFP_TRUNK_SKIP & 4)) return;
-    const int p = w8 + 8 * i;
-    if (p < G::PIX_PIECES) dma16<COH>(rs_in, isrc[i], (unsigned)(c * 64), st + (unsigned)(p << 10));
+    const int p = w8 - 1 + 7 * i;
+    if (w8 > 0 && p < G::PIX_PIECES) dma16<COH>(rs_in, isrc[i], (unsigned)(c * 64), st + (unsigned)(p << 10));
   };
-  const int pix_pieces = w8 < 7 ? 5 : 4;           // 39 = 7 x 5 + 4
+  const int pix_pieces = w8 == 0 ? 0 : (w8 <= 4 ? 6 : 5);      // 39 = 4 x 6 + 3 x 5
   // weight fragments of chunk c of the weight cursor's block -> weight stage at `st`: pieces w8 + 8 j < 18; with first = true also the block's
   // bias (128 B; loader 7's third slot) -> bias slot at `bst`
   auto dma_w = [&](int c, unsigned st, int j, bool first, unsigned bst) {
@@ -333,8 +337,8 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
   // last and belong to the step after next — they are NOT waited for at the end of the step that requests them)
   auto wait_keep = [&](int keep) {
     switch (keep) {
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
       case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
   };
@@ -472,9 +476,51 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
       __builtin_amdgcn_raw_buffer_store_b128(ov.u, rs_o, ok ? (rel * o_cs + ch0) * 2 : OOB, 0, AUXC);
     }
   };
+  // ---- the epilogue's other form. Global stores issue at ~14 B/clk per CU: an item's 32 KiB cost its compute waves ~4 us with the matrix pipe
+  // idle (76 us of a 108 us launch without the epilogue). So where the layer has no residual input (conv1..conv4 of every dense block) a compute
+  // wave only applies the activation, rounds to fp16 — the same values the register epilogue stores — and writes its eight rows into the
+  // pixel stage its item has just finished with (row R of the tile = KiB R of the stage); two steps later loader w reads rows w, 8 + w, 16 + w,
+  // 24 + w — exactly the KiBs its own next DMA pieces overwrite — and issues the stores beside the next item's MFMAs.
+  auto xchg_write = [&](unsigned char* xs, int act) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v[8];
+      v[0] = acc[i][0][0]; v[1] = acc[i][0][1]; v[2] = acc[i][0][2]; v[3] = acc[i][0][3];
+      v[4] = acc[i][1][0]; v[5] = acc[i][1][1]; v[6] = acc[i][1][2]; v[7] = acc[i][1][3];
+      if (act == ACT_LRELU) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], v[q] * 0.2f);
+      } else if (act == ACT_SILU) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = apply_act(v[q], ACT_SILU);
+      }
+      union { uint4 u; _Float16 h[8]; } ov;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ov.h[q] = (_Float16)v[q];
+      *reinterpret_cast<uint4*>(xs + ((8 * (wave & 3) + i) << 10) + lane * 16) = ov.u;
+    }
+  };
+  auto xchg_store = [&](const unsigned char* xs, const Item& it) {
+    const LPtr L = layers + it.layer;
+    const int o_cs = L->out_cs;
+    unsigned char* ob = reinterpret_cast<unsigned char*>(L->out) + ((long long)it.px0 * o_cs + L->out_coff) * 2;
+    const unsigned long long u = reinterpret_cast<unsigned long long>(ob);
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(((unsigned long long)rfl((unsigned)(u >> 32)) << 32) | rfl((unsigned)u)), 0, 0x7FFFFFF0, 0x00020000);
+    const int ox = it.x0 + pc, ch0 = it.nb * 32 + 8 * g;
+    u32x4 d[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) d[w] = *reinterpret_cast<const u32x4*>(xs + ((8 * w + w8) << 10) + lane * 16);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int oy = it.y0 + 8 * w + w8;
+      const bool ok = oy < it.H && ox < it.W;
+      __builtin_amdgcn_raw_buffer_store_b128(d[w], rs_o, ok ? ((unsigned)(oy * it.W + ox) * o_cs + ch0) * 2 : OOB, 0, AUXC);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the rows are in registers before this wave's next DMA pieces land on them
+  };
   auto publish = [&](int tile) {                   // every compute wave has drained its stores and the workgroup has met at a barrier since
     if ((FFP_TRUNK_SKIP & 64)) return;
-    if (COH && tid == 0) __hip_atomic_fetch_add(a.done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (COH && tid == 256) __hip_atomic_fetch_add(a.done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
   // ---- the walk: ONE body, instantiated per role — a compute wave's loop then carries no staging state and a loader's loop no accumulators (with
@@ -492,6 +538,11 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
   unsigned pix_next = 0;   // stream index of the next pixel chunk to request (pix_next > q: this step's chunk is in LDS or on its way)
   bool w_have = false;     // this step's weights have been requested (in the previous step)
   int pub_tile = -1;
+  unsigned pub_after = 0;  // ... once the barrier of stream step pub_after has been passed
+  bool pub_by_loader = false;
+  int x_age = 0;           // a finished tile sits in a pixel stage for the loaders: 1 in the step after its item's last, 2 in the step the loaders store it
+  unsigned x_q = 0;        // ... the stage of stream step x_q
+  Item x_item = cur;
   auto pstage = [&](unsigned n) { return lds0 + (n % 3u) * G::PIX; };
   // which (item, chunk) is step n of the stream? 0: the current item, 1: the next one, -1: not known yet
   auto step_of = [&](unsigned n, int& cc) {
@@ -512,6 +563,9 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
 #define TDUMP()
 #endif
   for (unsigned itn = 0;; ++itn) {
+    const int xa = x_age;                          // 1: the compute waves have just written a finished tile into stage x_q % 3 — hands off; 2: store it now
+    if (x_age) x_age = x_age == 2 ? 0 : 2;
+    if (LD && xa == 2) xchg_store(smem + (x_q % 3u) * G::PIX, x_item);
     // ---- operands of this step not requested yet (the walk's first step, after a late dependency, after a gap in the look-ahead): the loaders
     // request them now — and as much of the look-ahead as is known — and wait. Every wave takes the same branch (the cursors are wave-uniform).
     if (pix_next <= q || !w_have) {
@@ -519,11 +573,12 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
         int cc;
         const int which = step_of(pix_next, cc);
         if (which < 0) break;
+        if (xa == 1 && pix_next % 3u == x_q % 3u) break;       // that stage holds a finished tile the loaders have not read yet
         if constexpr (LD) {
           const int seq = ck + which;
           if (pix_item != seq) setup_pix(which ? nxt : cur, seq);
 #pragma unroll
-          for (int i = 0; i < 5; ++i) dma_pix(cc, pstage(pix_next), i);
+          for (int i = 0; i < 6; ++i) dma_pix(cc, pstage(pix_next), i);
         }
         ++pix_next;
       }
@@ -545,40 +600,50 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
     }
     const bool last = c == cur.NC - 1;                           // the item's last step
     const bool nxt_known = rfl(snap[itn & 1u]) != 0;             // is the item after the ones held READY? (wave 0's snapshot of the PREVIOUS iteration: uniform)
-    if (!LD && wave == 0) control_issue();
+    if (LD && wave == 4) control_issue();
     TSTAMP(0)
     // ---- what is requested while this step multiplies: the next step's weights (this item's next chunk, or the next item's first) and ONE
     // pixel chunk, up to two steps ahead
     int wc = c + 1, wwhich = 0;
     if (wc == cur.NC) { wc = 0; wwhich = have_nxt ? 1 : -1; }
-    int pcc = 0, pwhich = -1;
-    if (pix_next <= q + 2) pwhich = step_of(pix_next, pcc);
-    const unsigned p_idx = pix_next;
+    // (up to two when the look-ahead is behind: after a tile exchange kept a stage busy, after a late item)
+    const bool use_x = last && cur.xchg && wwhich == 1;          // the finished tile goes to the loaders through this step's pixel stage
     int npix = 0;
+    unsigned p_last = q;                                         // stream index of the last pixel chunk requested in this step
     if constexpr (LD) {
       if (wwhich == 1) setup_w(nxt);
-      if (pwhich >= 0 && pix_item != ck + pwhich) setup_pix(pwhich ? nxt : cur, ck + pwhich);
       TSTAMP(1)
       const unsigned wst = lds0 + G::WOFF + ((q + 1u) & 1u) * G::WB, bst = lds0 + G::BIAS + (unsigned)((ck + 1) & 1) * 1024u;
       if (wwhich >= 0) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) dma_w(wc, wst, j, wwhich == 1, bst);
       }
-      if (pwhich >= 0) {
+    }
+    for (int n_req = 0; n_req < 2 && pix_next <= q + 2; ++n_req) {
+      int pcc;
+      const int pwhich = step_of(pix_next, pcc);
+      if (pwhich < 0) break;
+      if (xa == 1 && pix_next % 3u == x_q % 3u) break;           // that stage holds a finished tile the loaders have not read yet
+      if constexpr (LD) {
+        if (pix_item != ck + pwhich) setup_pix(pwhich ? nxt : cur, ck + pwhich);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) dma_pix(pcc, pstage(p_idx), i);
-        // the pixel pieces are the youngest requests and belong to the step after next: they stay in flight over this step's end — unless the
-        // look-ahead had a gap and the chunk requested here is the NEXT step's
-        if (p_idx == q + 2u) npix = pix_pieces;
+        for (int i = 0; i < 6; ++i) dma_pix(pcc, pstage(pix_next), i);
       }
+      p_last = pix_next;
+      ++pix_next;
+    }
+    if constexpr (LD) {
+      // the pixel pieces of a chunk two steps ahead are the youngest requests: they stay in flight over this step's end (an older chunk requested
+      // in the same step, and this step's stores, complete under the same wait)
+      if (p_last == q + 2u) npix = pix_pieces;
       TSTAMP(2)
     } else {
       Epi ep = {};
-      if (last) ep = load_epi(cur);
+      if (last && !use_x) ep = load_epi(cur);
       TSTAMP(1)
       chunk(smem + (q % 3u) * G::PIX, smem + G::WOFF + (q & 1u) * G::WB);
       TSTAMP(2)
-      if (last) {
+      if (last && !use_x) {
         if (!(FFP_TRUNK_SKIP & 1)) {
           epilogue(cur, ep);
         } else {                                   // diagnostic build: keep the sums alive without the epilogue
@@ -587,7 +652,6 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
         }
       }
     }
-    if (pwhich >= 0) ++pix_next;
     const bool w_next_have = wwhich >= 0;
     if (!have_nxt && nxt_known) {                  // the next item's descriptor (LDS reads + scalar loads: they overlap the wait below)
       nxt = load_item(ck + 1);
@@ -599,14 +663,12 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
     // publish below relies on) and wave 0's control requests; an item's last step leaves its four stores in flight.
     if constexpr (LD) {
       wait_keep(npix);
+      if (wave == 4) control_consume();            // loader 0 stages no pixel pieces (npix = 0): everything it has asked for is back
     } else {
-      if (!last) {
-        wait_all();
-        if (wave == 0) control_consume();
-      }
+      if (!last) wait_all();
     }
     const bool switching = last && w_next_have;    // the stream runs on into the next item
-    if (!LD && tid == 0) {                         // is the item after the ones this workgroup will hold in the next iteration READY (and not held yet)?
+    if (LD && tid == 256) {                        // is the item after the ones this workgroup will hold in the next iteration READY (and not held yet)?
       const bool will_hold_next = have_nxt && !switching;
       snap[(itn + 1u) & 1u] = !will_hold_next && get4(s_st, (switching ? ck + 2 : ck + 1) & 3) == D_READY ? 1 : 0;
     }
@@ -616,29 +678,44 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
 #if FFP_TRUNK_DBG
     ++n_iter;
 #endif
-    if (pub_tile >= 0 && !last) {                  // the previous item: its stores were drained by this (non-final) step's full wait
-      if (!LD) publish(pub_tile);
+    // the previous item's tile becomes visible to its dependents once its stores have been drained: the compute waves' own stores by their full wait
+    // of a non-final step, the loaders' (tile exchange) by the counted wait of the step in which they issued them
+    if (pub_tile >= 0 && q >= pub_after && (pub_by_loader || !last)) {
+      if (LD) publish(pub_tile);
       pub_tile = -1;
     }
     ++q;
     w_have = w_next_have;
     if (!last) { ++c; continue; }
     // ---- the item is finished
-    if (!LD && tid == 0) desc[(ck & 3) * 16] = D_EMPTY;   // its slot: sequence ck + 4 will be fetched into it
-    if (!LD && wave == 0) put4(s_st, ck & 3, D_EMPTY);
+    if (LD && tid == 256) desc[(ck & 3) * 16] = D_EMPTY;  // its slot: sequence ck + 4 will be fetched into it
+    if (LD && wave == 4) put4(s_st, ck & 3, D_EMPTY);
     q0 += (unsigned)cur.NC;
     c = 0;
     if (switching) {
-      pub_tile = cur.tile;
+      if (pub_tile >= 0) {                         // cannot happen (every item has at least two steps); never lose a tile's publication
+        wait_all();
+        __syncthreads();
+        if (LD) publish(pub_tile);
+      }
+      pub_tile = cur.tile; pub_by_loader = use_x; pub_after = use_x ? q + 1u : q;       // q is already the next step's index
+      if (use_x) {
+        x_age = 1; x_q = q - 1u; x_item = cur;
+        if (!LD) xchg_write(smem + (x_q % 3u) * G::PIX, layers[cur.layer].act);
+      }
       cur = nxt; have_nxt = false; ++ck;
       if (!LD) init_acc(smem + G::BIAS + (ck & 1) * 1024);
       continue;
     }
     // the next item is not known or not ready (or there is none): finish this one for good, then wait for it
+    if (LD && x_age == 2) { xchg_store(smem + (x_q % 3u) * G::PIX, x_item); }          // (a tile still in a stage: store it before the walk stops or pauses)
+    x_age = 0;
     wait_all();
     __syncthreads();
-    if (!LD) publish(cur.tile);
-    if (!LD && wave == 0) control_wait(ck + 1);
+    if (LD && pub_tile >= 0) publish(pub_tile);
+    pub_tile = -1;
+    if (LD) publish(cur.tile);
+    if (LD && wave == 4) control_wait(ck + 1);
     __syncthreads();
     if (rfl(desc[((ck + 1) & 3) * 16]) != D_READY) { TDUMP() return; }
     ++ck;
@@ -646,11 +723,11 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
     have_nxt = false;
     pix_next = q;                                  // nothing of the new item has been requested: the top of the loop does it and waits
     w_have = false;
-    if (!LD && tid == 0) { snap[0] = 0; snap[1] = 0; }
+    if (LD && tid == 256) { snap[0] = 0; snap[1] = 0; }
     __syncthreads();
   }
   };
-  if (wave == 0) control_wait(0);
+  if (wave == 4) control_wait(0);
   __syncthreads();
   if (loader) walk(std::true_type{});
   else walk(std::false_type{});
