@@ -34,7 +34,7 @@ PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3, "f32x3": 2500.0 / 3}
 SUSTAINED_TFLOPS = {"f16": 1908.0, "f32x3": 1677.0 / 3}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -75,7 +75,10 @@ def parse():
     ap.add_argument("--secondary-steps", type=int, default=20)
     ap.add_argument("--secondary-only", default="", help="comma-separated names: measure only these secondary rows (experiments)")
     ap.add_argument("--sr-exclusive", action="store_true", help="experiment: wait for every SR batch before the next detection group (no overlap of the two streams)")
-    return ap.parse_args()
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed run: the pipelined loop's outputs (merged rows, crop boxes, enhanced crops; JPEG files with jpeg_io) over 25 steps against "
+                         "synchronous calls on fresh buffers, byte for byte, with 1 lane, 2 lanes and once with JPEG decode/encode in the span -> \"verify\" in the JSON line")
+    return ap.parse_args(argv)
 
 
 def _cpu_budget():
@@ -347,10 +350,24 @@ class Runner:
             out = self.pending.pop("out")
             self.pending.pop("slots", None)
             ids = self.pending.pop("frame_ids", ())
+            v = self.pending.pop("v", None)
+            if v is not None:                          # verify: keep every enhanced crop of the batch, by frame
+                offs_v = self.pending.pop("offs")
+                host = out[:int(offs_v[-1])].cpu().numpy()
+                k = 0
+                for fid, bx in v:
+                    self.rec[fid]["crops"] = [host[int(offs_v[k + j]):int(offs_v[k + j + 1])].copy() for j in range(len(bx))]
+                    k += len(bx)
             if self.jpeg_io:
                 offs, hs, ws = self.pending.pop("meta")
+                keep = self.pending.pop("keep")
                 files = self._lib.jpeg_encode_batch_dev(out.data_ptr(), offs, hs, ws, 95, bgr=True, device=self.ctx["local_rank"])     # enhanced crops -> .jpg bytes on the host
                 self.jpeg_bytes_out += sum(len(f) for f in files)
+                if v is not None:
+                    it, k = iter(files), 0
+                    for fid, bx in v:
+                        self.rec[fid]["files"] = [bytes(next(it)) if keep[k + j] else None for j in range(len(bx))]
+                        k += len(bx)
                 return
             if self.host_sr is None or self.host_sr.numel() < out.numel():
                 self.host_sr = self.torch.empty((int(out.numel() * 1.5),), dtype=self.torch.uint8).pin_memory()
@@ -367,6 +384,7 @@ class Runner:
         q = [x[1:3] for x in self.queue if len(x[2])]
         keys = {x[0] for x in self.queue if len(x[2])}
         ids = [x[3] for x in self.queue]
+        vmeta = [(x[3], x[2]) for x in self.queue if len(x[2])] if self.verify else None
         self.queue.clear()
         if not q:
             t1 = time.perf_counter()
@@ -380,12 +398,15 @@ class Runner:
         self.pending["out"] = out
         self.pending["slots"] = keys
         self.pending["frame_ids"] = ids
+        if vmeta is not None:
+            self.pending["v"], self.pending["offs"] = vmeta, np.array(offs, copy=True)
         if self.jpeg_io:
             bx = np.concatenate([x[1] for x in q], 0).astype(np.int64)
             bx = np.stack([np.clip(bx[:, 0], 0, self.W), np.clip(bx[:, 1], 0, self.H), np.clip(bx[:, 2], 0, self.W), np.clip(bx[:, 3], 0, self.H)], 1)   # as the library clamps
             hs, ws = (bx[:, 3] - bx[:, 1]) * self.pipe.sr.scale, (bx[:, 2] - bx[:, 0]) * self.pipe.sr.scale
             keep = (hs > 0) & (ws > 0)
             self.pending["meta"] = (np.asarray(offs[:len(bx)], np.int64)[keep], hs[keep], ws[keep])
+            self.pending["keep"] = keep
         self.sr_px += int(sum(int((b[:, 2] - b[:, 0]) @ (b[:, 3] - b[:, 1])) for _, b in q))
 
     # ---- one group of DB steps ---------------------------------------------------------------------------------------------------
@@ -446,7 +467,11 @@ class Runner:
                         own = self.pipeline.lpt_assign((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]), self.world) == self.rank
                         boxes = boxes[own]
                     self.queue.append((slot_key, sf[f * H:(f + 1) * H], boxes, (i, fb)))
+                    if self.verify:
+                        self.rec[(i, fb)] = {"rows": rows.copy(), "boxes": np.array(boxes, copy=True)}
                 else:
+                    if self.verify:
+                        self.rec[(i, fb)] = {"rows": rows.copy(), "boxes": None}
                     self.lat.append(time.perf_counter() - self.lat_t0.pop((i, fb)))
             if a.sr_crops > 0 and (len(self.queue) >= self.SB or last):
                 prof = self.prof_flush is not None and self.flush_no == self.prof_flush     # the kernel times of ONE whole SR batch
@@ -516,6 +541,92 @@ class Runner:
             t.join()
         if errs:
             raise errs[0]
+
+    def verify_against_synchronous(self, n_steps):
+        """What the pipelined loop (frame-slot ring, copy / detector / enhancer streams, lanes, an SR batch in flight while the next groups are
+        detected) produced for every frame of loop(n_steps), against the same calls made one at a time on fresh buffers with a device
+        synchronisation after each: the group's frames in one new tensor, detect, merge per frame, the crops of ONE frame per enhancer call (the
+        pipelined loop batches SB frames: a crop's bytes must not depend on its batch), JPEG files encoded per frame. Byte for byte."""
+        torch, pipe = self.torch, self.pipe
+        assert self.mode == "local" and self.world == 1, "the verification loop is a single-process check"
+        rec = {}
+        for r in [self] + self.sub:
+            rec.update(r.rec)
+        H, W, Bl, hf = self.H, self.W, self.Bl, self.ctx["host_frames"]
+        fbytes = H * W * 3
+        out = {"steps": n_steps, "lanes": self.n_lanes, "det_batch_frames": self.DB, "sr_batch_frames": self.SB, "jpeg_io": bool(self.jpeg_io), "frames": 0, "crops": 0,
+               "rows_equal": True, "boxes_equal": True, "crops_equal": True, "files_equal": True if self.jpeg_io else None, "mismatches": []}
+
+        def bad(key, what, fid):
+            out[key] = False
+            if len(out["mismatches"]) < 8:
+                out["mismatches"].append(f"{what} of frame {fid}")
+
+        for gi, (g0, gsz) in enumerate(self.groups(n_steps)):
+            variant, nf = gi % len(hf), Bl * gsz
+            if self.jpeg_io:
+                sf = torch.empty((nf * H, W, 3), dtype=torch.uint8, device=self.dev)
+                for f in range(nf):
+                    self._lib.jpeg_decode_dev(self.jpegs[self.frame_of(variant, f)], sf.data_ptr() + f * fbytes, W * 3, fbytes, False, self.ctx["local_rank"])
+            else:
+                sf = torch.from_numpy(np.concatenate([hf[self.frame_of(variant, f)] for f in range(nf)], 0)).to(self.dev)
+            torch.cuda.synchronize(self.dev)
+            dets, counts, L, gathered = pipe.detect(sf, H, W, nf, exchange=self.exchange, mode=self.mode)
+            torch.cuda.synchronize(self.dev)
+            for i in range(g0, g0 + gsz):
+                for fb in range(Bl):
+                    f, fid = (i - g0) * Bl + fb, (i, fb)
+                    got = rec.get(fid)
+                    if got is None:
+                        bad("rows_equal", "no record", fid)
+                        continue
+                    out["frames"] += 1
+                    rows_d, n_d = pipe.merge_frame_of(dets, counts, L, f, gathered)
+                    n = pipe.merged_count(n_d)
+                    rows = rows_d[:n].cpu().numpy().copy()
+                    rows[:, [1, 3]] -= f * H
+                    if not np.array_equal(rows, got["rows"]):
+                        bad("rows_equal", "merged rows", fid)
+                    if self.args.sr_crops <= 0:
+                        continue
+                    boxes = self.crop_boxes(rows, i * self.B + self.rank)
+                    if not np.array_equal(boxes, got["boxes"]):
+                        bad("boxes_equal", "crop boxes", fid)
+                        continue
+                    if not len(boxes):
+                        continue
+                    o, offs = pipe.enhance_crops(sf[f * H:(f + 1) * H], H, W, boxes, wait=True, slot=0)
+                    torch.cuda.synchronize(self.dev)
+                    host = o[:int(offs[-1])].cpu().numpy()
+                    crops = got.get("crops")
+                    if crops is None or len(crops) != len(boxes):
+                        bad("crops_equal", "crop list", fid)
+                        continue
+                    for j in range(len(boxes)):
+                        out["crops"] += 1
+                        if not np.array_equal(host[int(offs[j]):int(offs[j + 1])], crops[j]):
+                            bad("crops_equal", f"crop {j}", fid)
+                    if self.jpeg_io:
+                        bx = boxes.astype(np.int64)
+                        bx = np.stack([np.clip(bx[:, 0], 0, W), np.clip(bx[:, 1], 0, H), np.clip(bx[:, 2], 0, W), np.clip(bx[:, 3], 0, H)], 1)
+                        hs, ws = (bx[:, 3] - bx[:, 1]) * pipe.sr.scale, (bx[:, 2] - bx[:, 0]) * pipe.sr.scale
+                        keep = (hs > 0) & (ws > 0)
+                        files = self._lib.jpeg_encode_batch_dev(o.data_ptr(), np.asarray(offs[:len(bx)], np.int64)[keep], hs[keep], ws[keep], 95, bgr=True, device=self.ctx["local_rank"])
+                        mine = [x for x in got.get("files", []) if x is not None]
+                        if len(mine) != len(files) or any(bytes(a) != b for a, b in zip(files, mine)):
+                            bad("files_equal", "JPEG files", fid)
+        out["ok"] = bool(out["frames"] == n_steps * self.Bl and out["rows_equal"] and out["boxes_equal"] and out["crops_equal"] and out["files_equal"] in (True, None)
+                         and (self.args.sr_crops <= 0 or out["crops"] > 0))
+        return out
+
+    def run_verify(self, steps):
+        """Plans first (untimed set-up), then the pipelined loop with recording, then the synchronous pass."""
+        self.setup(2, steps)
+        for r in [self] + self.sub:
+            r.rec.clear()
+        self.loop(steps)
+        self.torch.cuda.synchronize(self.dev)
+        return self.verify_against_synchronous(steps)
 
     def barrier(self):
         import torch.distributed as dist
@@ -595,6 +706,29 @@ class Runner:
                 + (f", Real-ESRGAN x4 on {a.sr_crops} crops/frame (sizes {self.sr_sizes})" if a.sr_crops > 0 else ", no SR"))
 
 
+def make_ctx(args, rank=0, world=1, local_rank=0, dev=None, backend="nccl"):
+    """What every Runner of a process shares: the random-init weights of BASELINE.json's architectures and the synthetic frames."""
+    import torch
+    from ffp_amd import synth
+    return {"rank": rank, "world": world, "local_rank": local_rank, "dev": dev if dev is not None else torch.device("cuda", local_rank), "backend": backend,
+            "det_w": synth.yolo11_pose_weights(args.arch), "sr_w": synth.rrdbnet_weights(4, 23) if args.sr_crops > 0 else None,
+            "host_frames": [synth.synthetic_frame(args.height, args.width, seed=i) for i in range(max(1, args.distinct_frames))]}
+
+
+def verify_rows(args, ctx, pipes, steps=25):
+    """--verify: pipelined against synchronous, DB / SB as configured (5 / 10 by default), with 1 lane, 2 lanes, and 1 lane with JPEG in and out."""
+    rows = {}
+    for name, kw in (("one_lane", dict(lanes=1)), ("two_lanes", dict(lanes=2)), ("one_lane_jpeg_io", dict(lanes=1, jpeg_io=True))):
+        if kw.get("jpeg_io") and args.sr_crops <= 0:
+            continue
+        r = Runner(args, ctx, pipes=pipes, verify=True, **kw)
+        try:
+            rows[name] = r.run_verify(steps)
+        finally:
+            r.close()
+    return rows
+
+
 def main():
     args = parse()
     import torch
@@ -620,9 +754,7 @@ def main():
             dist.init_process_group(backend)
 
     H, W = args.height, args.width
-    ctx = {"rank": rank, "world": world, "local_rank": local_rank, "dev": dev, "backend": backend,
-           "det_w": synth.yolo11_pose_weights(args.arch), "sr_w": synth.rrdbnet_weights(4, 23) if args.sr_crops > 0 else None,
-           "host_frames": [synth.synthetic_frame(H, W, seed=i) for i in range(max(1, args.distinct_frames))]}
+    ctx = make_ctx(args, rank, world, local_rank, dev, backend)
 
     main_r = Runner(args, ctx)
     dt = main_r.timed(args.warmup, args.steps)
@@ -789,6 +921,10 @@ def main():
             "roofline": roof,
             "secondary": secondary,
         }
+        if world == 1 and args.verify:
+            res["verify"] = verify_rows(args, ctx, pipes, steps=max(25, args.steps))
+            if not all(v["ok"] for v in res["verify"].values()):
+                print("[bench] --verify: the pipelined loop's outputs differ from the synchronous calls", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             base_r = Runner(args, ctx, pipes=pipes, resident=True, lanes=1)
             sf, _ = base_r.upload(0, 1)

@@ -87,7 +87,7 @@ class SrEngine {
   hipStream_t st_ = nullptr;
   hipEvent_t ev_[2];
   bool pending_ = false;
-  bool fused_body_ = true;
+  bool fused_body_ = false;
   size_t weight_bytes_ = 0;
 };
 

@@ -202,8 +202,9 @@ int ffp_sr_enhance_crops_multi_dev_async(ffp_sr* s, int n_frames, const uint8_t*
  * not grow it), out_last_graph tells whether the last call replayed a captured hipGraph (1) or launched eagerly (0). */
 int ffp_sr_plan_state(ffp_sr* s, int32_t* out_plans_built, int32_t* out_last_graph);
 /* The body of RRDBNet (the 345 convs of the residual dense blocks constructed at utils/enhancer.py:121-128) as ONE persistent launch
- * with per-tile dependency counters (1, the default in fp16) or as one launch per layer (0). Results are bit-identical either way;
- * the per-layer form is the fused form's parity oracle and A/B partner. Drops the resident plans. */
+ * with per-tile dependency counters (1; fp16 only) or as one launch per layer (0, the default: the faster of the two on MI355X as
+ * measured in round 4, profiles/r04_sr_batch_sweep.txt; FFP_TRUNK=1 in the environment makes 1 the default). Results are bit-identical
+ * either way; each form is the other's parity oracle and A/B partner. Drops the resident plans. */
 int ffp_sr_set_fused_body(ffp_sr* s, int on);
 /* Device memory a handle holds: the packed weights and the resident plans (activations + tables; the detector keeps at most 8 plans
  * and FFP_DET_PLAN_GIB (default 64) GiB of them, the enhancer at most 4 capacity buckets, least recently used first out). The
