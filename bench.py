@@ -715,6 +715,128 @@ def make_ctx(args, rank=0, world=1, local_rank=0, dev=None, backend="nccl"):
             "host_frames": [synth.synthetic_frame(args.height, args.width, seed=i) for i in range(max(1, args.distinct_frames))]}
 
 
+COMPAT = os.path.join(ROOT, "face-detection-with-yolov11-sahi-and-real-esrgan_amd", "compat")
+
+
+def compat_api_row(args, ctx, steps):
+    """secondary.through_compat_api: the reference's own loop, one frame and one crop at a time, through the drop-in modules under compat/ —
+    `get_sliced_prediction(image, detection_model, slice_height, slice_width, overlap…)` as pipeline_v4_yolo/app_yolo_sahi.py:49-56 calls it, then
+    `FaceEnhancer.enhance_image(crop)` per crop as pipeline_v1_detection_first/app_v1.py:91-104 -> utils/enhancer.py:344-391 does. Frames come
+    from memory (an ndarray) and, second figure, from .jpg files on disk read the way the reference reads them (PIL inside SAHI, cv2.imread
+    for the crops). Same frames, crop law and seeds as the headline; nothing batched across frames or crops."""
+    import contextlib
+    import io
+    import tempfile
+    from ffp_amd import _lib, pipeline
+    sys.path.insert(0, COMPAT)
+    quiet = io.StringIO()
+    try:
+        import cv2                                                              # compat/cv2: imread / imwrite on this build's JPEG codec
+        from sahi.predict import get_sliced_prediction
+        from utils.enhancer import FaceEnhancer
+        from utils.yolo_wrapper import YOLOv11PoseDetectionModel
+        with contextlib.redirect_stdout(quiet):
+            model = YOLOv11PoseDetectionModel(model_path=ctx["det_w"], confidence_threshold=args.conf, device=f"cuda:{ctx['local_rank']}", image_size=args.imgsz)
+            enh = FaceEnhancer("RealESRGAN_x4plus", model_path=ctx["sr_w"], scale=4, tile=400, half=True) if args.sr_crops > 0 else None
+        hf, H, W = ctx["host_frames"], args.height, args.width
+        tm = {"sliced_prediction": 0.0, "enhance_crops": 0.0, "read_crop_source": 0.0}
+        state = {"batched": False}
+
+        def one(k, src):
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(quiet):
+                res = get_sliced_prediction(src, model, slice_height=args.slice, slice_width=args.slice, overlap_height_ratio=args.overlap,
+                                            overlap_width_ratio=args.overlap, postprocess_type=args.pp_type, postprocess_class_agnostic=args.class_agnostic, verbose=0)
+            t1 = time.perf_counter()
+            tm["sliced_prediction"] += t1 - t0
+            preds = sorted(res.object_prediction_list, key=lambda p: -p.score.value)
+            state["detections"] = len(preds)
+            if enh is None:
+                return
+            bgr = cv2.imread(src) if isinstance(src, str) else src[..., ::-1]      # app_v1 reads the picture once more with cv2 for the crops (BGR)
+            t2 = time.perf_counter()
+            tm["read_crop_source"] += t2 - t1
+            rows = np.asarray([list(p.bbox.to_xyxy()) + [p.score.value] for p in preds], np.float32).reshape(-1, 5)
+            boxes = pipeline.crop_boxes_for_sr(rows, H, W, args.sr_crops, pipeline.sr_crop_sizes(args.sr_crops, seed=1000 + k), seed=k)
+            crops = [np.ascontiguousarray(bgr[y0:y1, x0:x1]) for x0, y0, x1, y1 in boxes]
+            with contextlib.redirect_stdout(quiet):
+                outs = enh.enhance_images(crops) if state["batched"] else [enh.enhance_image(c) for c in crops]
+            for c, (out, ok) in zip(crops, outs):
+                assert ok and out.shape[0] == 4 * c.shape[0]
+            tm["enhance_crops"] += time.perf_counter() - t2
+
+        def timed(srcs):
+            for k in range(2):
+                one(k, srcs[k % len(srcs)])
+            for key in tm:
+                tm[key] = 0.0
+            t0 = time.perf_counter()
+            for k in range(steps):
+                one(k, srcs[k % len(srcs)])
+            dt = time.perf_counter() - t0
+            return steps / dt, {key: round(v / steps * 1e3, 3) for key, v in tm.items()}
+
+        fps_mem, st_mem = timed(hf)
+        state["batched"] = True
+        fps_bat, st_bat = timed(hf) if enh is not None else (None, None)
+        state["batched"] = False
+        with tempfile.TemporaryDirectory() as td:
+            paths = []
+            for i, f in enumerate(hf):
+                paths.append(os.path.join(td, f"frame{i}.jpg"))
+                with open(paths[-1], "wb") as fh:
+                    fh.write(_lib.jpeg_encode(f, 95, bgr=False))
+            fps_jpg, st_jpg = timed(paths)
+        return {"value": round(fps_mem, 3), "unit": "frames/s", "steps": steps, "frames": "ndarray in host memory", "host_stage_ms_per_frame": st_mem,
+                "from_jpg_files": {"value": round(fps_jpg, 3), "unit": "frames/s", "host_stage_ms_per_frame": st_jpg},
+                "crops_as_one_batch": ({"value": round(fps_bat, 3), "unit": "frames/s", "host_stage_ms_per_frame": st_bat,
+                                        "note": "FaceEnhancer.enhance_images (extension; what compat's enhance_face_crops_batch does inside): the frame's crops as one ragged GPU "
+                                                "batch instead of one synchronous enhance_image per crop"} if fps_bat else None),
+                "note": "enhance_image is synchronous per crop by signature (it returns the pixels): 32 crops = 32 dependent passes through 349 conv launches, "
+                        "about 3 ms each however small the crop; the detection half runs at the frame_by_frame rate",
+                "detections_last_frame": state.get("detections"),
+                "calls": "sahi.predict.get_sliced_prediction + utils.enhancer.FaceEnhancer.enhance_image per crop (compat/), one frame and one crop at a time"}
+    finally:
+        sys.path.remove(COMPAT)
+        for m in [k for k in sys.modules if k.split(".")[0] in ("sahi", "utils", "cv2", "eval")]:
+            if getattr(sys.modules[m], "__file__", "") and COMPAT in (sys.modules[m].__file__ or ""):
+                del sys.modules[m]
+
+
+def config1_row(args, ctx):
+    """secondary.config1_640_yolo11n — BASELINE configs[0] as scripts/inference_time.py:43-56 measures it: one 640 x 640 image, YOLO11n, no slicing,
+    no SR; `model.predict(img, imgsz=640)` once as warm-up, then ONE timed call (fps = 1 / that call). Through compat's YOLO (utils/yolo_wrapper.py:55's
+    `YOLO(model_path)`), image handed over as PIL like the script does. The median of 20 further calls is given beside it."""
+    import contextlib
+    import io
+    from PIL import Image
+    from ffp_amd import synth
+    sys.path.insert(0, COMPAT)
+    try:
+        from utils.yolo_wrapper import YOLO
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = YOLO(synth.yolo11_pose_weights("n"), device=f"cuda:{ctx['local_rank']}")
+        img = Image.fromarray(synth.synthetic_frame(640, 640, seed=3, n_blobs=12))
+        model.predict(img, imgsz=640, device=f"cuda:{ctx['local_rank']}", verbose=False)
+        t0 = time.time()
+        r = model.predict(img, imgsz=640, device=f"cuda:{ctx['local_rank']}", verbose=False)
+        first = time.time() - t0
+        more = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            model.predict(img, imgsz=640, device=f"cuda:{ctx['local_rank']}", verbose=False)
+            more.append(time.perf_counter() - t0)
+        del model
+        return {"value": round(1.0 / first, 2), "unit": "images/s", "ms": round(first * 1e3, 3), "median_ms_of_20_more": round(float(np.median(more)) * 1e3, 3),
+                "workload": "one 640x640 image, YOLO11n-pose (random-init), no SAHI, no SR; model.predict after one warm-up call (scripts/inference_time.py:43-56)",
+                "detections": int(len(r[0].boxes))}
+    finally:
+        sys.path.remove(COMPAT)
+        for m in [k for k in sys.modules if k.split(".")[0] in ("sahi", "utils", "cv2", "eval")]:
+            if getattr(sys.modules[m], "__file__", "") and COMPAT in (sys.modules[m].__file__ or ""):
+                del sys.modules[m]
+
+
 def verify_rows(args, ctx, pipes, steps=25):
     """--verify: pipelined against synchronous, DB / SB as configured (5 / 10 by default), with 1 lane, 2 lanes, and 1 lane with JPEG in and out."""
     rows = {}
@@ -837,6 +959,24 @@ def main():
             sec("two_lanes", lanes=2)
             sec("two_lanes_steps_200", lanes=2, steps=200)
         sec("frames_resident_in_hbm", resident=True)
+        def sec_fn(name, fn):
+            if only and name not in only:
+                secondary[name] = {"value": None, "skipped": "--secondary-only"}
+                return
+            try:
+                secondary[name] = fn()
+            except Exception as e:      # noqa: BLE001
+                secondary[name] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+                print(f"[bench] secondary row {name} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            torch.cuda.empty_cache()
+
+        if world == 1:
+            # the drop-in API itself (the pipeline objects above are this build's own host side): what a caller of the reference's functions gets
+            sec_fn("through_compat_api", lambda: compat_api_row(args, ctx, min(ss, 20)))
+            fb, ca = secondary.get("frame_by_frame", {}).get("value"), secondary.get("through_compat_api", {}).get("value")
+            if fb and ca:
+                secondary["through_compat_api"]["vs_frame_by_frame"] = round(ca / fb, 3)
+            sec_fn("config1_640_yolo11n", lambda: config1_row(args, ctx))
         if world == 1:
             # the other BASELINE configs on the final tree (config 3 is the headline; 4 and the 8-GPU part of 5 need the driver's node)
             sec("config2_detect_only", workload={"sr_crops": 0})           # single 4K image, YOLO11s, SAHI 512 / 0.2, no SR

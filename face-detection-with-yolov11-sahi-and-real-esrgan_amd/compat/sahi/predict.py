@@ -15,7 +15,7 @@ import numpy as np
 from sahi.postprocess.combine import GreedyNMMPostprocess, LSNMSPostprocess, NMMPostprocess, NMSPostprocess, PostprocessPredictions
 from sahi.prediction import ObjectPrediction, PredictionResult
 from sahi.slicing import slice_image
-from sahi.utils.cv import read_image_as_pil
+from sahi.utils.cv import read_image_as_array
 
 POSTPROCESS_NAME_TO_CLASS = {"GREEDYNMM": GreedyNMMPostprocess, "NMM": NMMPostprocess, "NMS": NMSPostprocess, "LSNMS": LSNMSPostprocess}
 
@@ -28,12 +28,12 @@ def filter_predictions(object_prediction_list, exclude_classes_by_name, exclude_
 def get_prediction(image, detection_model, shift_amount: list = [0, 0], full_shape=None, postprocess: Optional[PostprocessPredictions] = None,
                    verbose: int = 0, exclude_classes_by_name: Optional[List[str]] = None, exclude_classes_by_id: Optional[List[int]] = None) -> PredictionResult:
     durations = dict()
-    pil = read_image_as_pil(image)
+    arr = read_image_as_array(image)
     t0 = time.time()
-    detection_model.perform_inference(np.ascontiguousarray(pil))
+    detection_model.perform_inference(np.ascontiguousarray(arr))
     durations["prediction"] = time.time() - t0
     if full_shape is None:
-        full_shape = [pil.height, pil.width]
+        full_shape = [arr.shape[0], arr.shape[1]]
     t0 = time.time()
     detection_model.convert_original_predictions(shift_amount=shift_amount, full_shape=full_shape)
     preds = filter_predictions(detection_model.object_prediction_list, exclude_classes_by_name, exclude_classes_by_id)

@@ -56,10 +56,29 @@ class ObjectPrediction(ObjectAnnotation):
 
 class PredictionResult:
     def __init__(self, object_prediction_list: List[ObjectPrediction], image, durations_in_seconds: Dict[str, Any] = dict()):
-        self.image = read_image_as_pil(image)
-        self.image_width, self.image_height = self.image.size
+        # the PIL copy of the picture (docs sahi/prediction.py:160-165) is made when somebody asks for it: the detection loop itself never does
+        self._image_src, self._image = image, None
+        self._size = (int(image.shape[1]), int(image.shape[0])) if isinstance(image, np.ndarray) and image.ndim == 3 and image.shape[2] <= 4 else None
         self.object_prediction_list = object_prediction_list
         self.durations_in_seconds = durations_in_seconds
+
+    @property
+    def image(self):
+        if self._image is None:
+            self._image = read_image_as_pil(self._image_src)
+        return self._image
+
+    @image.setter
+    def image(self, value):
+        self._image, self._size = value, None
+
+    @property
+    def image_width(self):
+        return self._size[0] if self._size else self.image.size[0]
+
+    @property
+    def image_height(self):
+        return self._size[1] if self._size else self.image.size[1]
 
     def to_coco_annotations(self):
         return [{"bbox": p.bbox.to_xywh(), "score": p.score.value, "category_id": p.category.id, "category_name": p.category.name}

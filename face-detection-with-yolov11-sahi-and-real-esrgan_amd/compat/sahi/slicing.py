@@ -7,7 +7,7 @@ import numpy as np
 
 import ffp_amd  # noqa: F401
 from ffp_amd import _lib
-from sahi.utils.cv import read_image_as_pil
+from sahi.utils.cv import read_image_as_array
 
 
 def get_slice_bboxes(image_height: int, image_width: int, slice_height: Optional[int] = None, slice_width: Optional[int] = None,
@@ -30,8 +30,7 @@ class SliceImageResult:
 
 def slice_image(image, output_file_name=None, output_dir=None, slice_height=None, slice_width=None, overlap_height_ratio=0.2,
                 overlap_width_ratio=0.2, auto_slice_resolution=True, **_ignored) -> SliceImageResult:
-    pil = read_image_as_pil(image)
-    arr = np.asarray(pil)
+    arr = read_image_as_array(image)
     h, w = arr.shape[:2]
     res = SliceImageResult([h, w], output_dir)
     for x0, y0, x1, y1 in get_slice_bboxes(h, w, slice_height, slice_width, auto_slice_resolution, overlap_height_ratio, overlap_width_ratio):
