@@ -64,11 +64,14 @@ def parse(argv=None):
                     help="frames whose crops are enhanced together as one ragged Real-ESRGAN batch (1: per frame)")
     ap.add_argument("--det-batch-frames", type=int, default=5,
                     help="consecutive steps whose frames are detected together as one ragged batch of slices (1: per step)")
-    ap.add_argument("--lanes", type=int, default=1,
+    ap.add_argument("--lanes", type=int, default=2,
                     help="pipeline lanes per process: L detector + enhancer handle pairs driven by L host threads, detection groups dealt round-robin "
-                         "(their kernels interleave on the card: +4-6 %% frames/s, see secondary.two_lanes); 1 = one lane, the headline's configuration — "
-                         "with several lanes the event-timed launches of the dominant kernel overlap another lane's kernels and its roofline line stops "
-                         "describing the kernel. Only where the ranks run independent frames (no collective in the loop)")
+                         "(their kernels interleave on the card; secondary.one_lane is the same loop on one lane). The kernel events behind `roofline` are "
+                         "taken on ONE lane in an extra profiled pass after the timed region, with the card to itself. Only where the ranks run independent "
+                         "frames (no collective in the loop): other layouts run one lane")
+    ap.add_argument("--conv-totals", action="store_true",
+                    help="count launches, algorithmic FLOPs and bytes of every conv launch of the process (ffp_conv_totals_*) and print them as \"conv_totals\": "
+                         "what tools/pmc_traffic.py needs beside a rocprofv3 --pmc pass of this same command")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", action="store_true", help="CPU baseline on a bounded sample (3 slices + 3 crops) instead of one whole frame")
     ap.add_argument("--no-secondary", action="store_true")
@@ -664,7 +667,7 @@ class Runner:
                 r.jpeg_bytes_in = r.jpeg_bytes_out = 0
                 r.frames_in = 0
         t0 = time.perf_counter()
-        self.loop(steps, profile_last=profile_last)
+        self.loop(steps)                               # nothing is profiled inside the timed region
         self.barrier()
         dt = time.perf_counter() - t0
         if self.world > 1:
@@ -684,7 +687,28 @@ class Runner:
             for key in ("boxes_frame0",):
                 if key in r.state and key not in self.state:
                     self.state[key] = r.state[key]
+        if profile_last:
+            self.profile_pass()
         return dt
+
+    def profile_pass(self):
+        """The kernel events behind `roofline` / `conv_profile_last_step`: ONE extra pass after the timed region, on lane 0 alone (no other lane's
+        kernels beside the launches that are timed), over the first max(SB, 2 DB) steps of the loop — the same frames, crops and seeds, one full
+        SR batch. Its last detection group and its last full SR batch run eagerly with an event pair around every conv launch."""
+        keep = (self.sub, self.n_lanes, self.tm, self.lat, self.lat_t0, self.sr_px, dict(self.state))
+        jp = (self.jpeg_bytes_in, self.jpeg_bytes_out, getattr(self, "frames_in", 0)) if self.jpeg_io else None
+        self.sub, self.n_lanes, self.tm, self.lat, self.lat_t0 = [], 1, {}, [], {}
+        self._wait_for = []
+        try:
+            n = -(-max(self.SB, 2 * self.DB) // self.Bl)
+            self.loop_own(n, profile_last=True)
+            self.torch.cuda.synchronize(self.dev)
+        finally:
+            self.sub, self.n_lanes, self.tm, self.lat, self.lat_t0, self.sr_px, self.state = keep
+            if jp:
+                self.jpeg_bytes_in, self.jpeg_bytes_out, self.frames_in = jp
+        self.prof_pipe = self.pipe
+        self.profile_steps = n
 
     def report(self, steps):
         """Per-rank view of the timed loop: host wall time per stage (ms per step), per-frame latency percentiles."""
@@ -877,9 +901,21 @@ def main():
 
     H, W = args.height, args.width
     ctx = make_ctx(args, rank, world, local_rank, dev, backend)
+    if args.conv_totals:
+        _lib.conv_totals_enable(True)
+    hbm_peak = [0]
+
+    def sample_hbm():
+        """Bytes in use on the card right now (every process, every allocator: hipMemGetInfo), kept as the maximum seen at the sampling points:
+        after the headline's timed loop and at the end of every secondary row, before the row's handles are released."""
+        free, total = torch.cuda.mem_get_info(dev)
+        hbm_peak[0] = max(hbm_peak[0], int(total - free))
+        return int(total - free)
 
     main_r = Runner(args, ctx)
     dt = main_r.timed(args.warmup, args.steps)
+    hbm_headline = sample_hbm()
+    main_mem = main_r.mem()
     B = main_r.B
     fps = B * args.steps / dt
     main_report = main_r.report(args.steps)
@@ -931,7 +967,8 @@ def main():
                 rep = r.report(steps_r)
                 secondary[name] = {"value": round(r.B * steps_r / d, 3), "unit": "frames/s", "ms_per_step": round(d / steps_r * 1e3, 3), "steps": steps_r, "workload": r.describe(),
                                    "frames_per_step": r.B, "det_batch_frames": r.DB, "sr_batch_frames": r.SB, "lanes": r.n_lanes, "mode": r.mode, "gathered": bool(r.state.get("gathered", False)),
-                                   "latency_ms_rank0": rep[0]["latency_ms"], "host_stage_ms_per_step_rank0": rep[0]["stage_ms_per_step"], "hbm_bytes": r.mem()}
+                                   "latency_ms_rank0": rep[0]["latency_ms"], "host_stage_ms_per_step_rank0": rep[0]["stage_ms_per_step"], "hbm_bytes": r.mem(),
+                                   "hbm_bytes_in_use_on_card": sample_hbm()}
                 if world > 1:
                     secondary[name]["per_rank"] = rep
                 if prof_sr and r.prof_pipe.sr is not None:         # the dominant kernel at THIS row's launch sizes
@@ -952,12 +989,16 @@ def main():
         # the reference's own order: strictly one frame, one SR pass at a time (docs sahi/predict.py:226,270) — nothing batched across frames
         sec("frame_by_frame", det_batch=1, sr_batch=1, profile_sr=True, lanes=1)      # one lane: never two frames on the card at once
         sec("steps_200", steps=200)                       # the headline configuration over a 10x longer timed region
-        if main_r.n_lanes == 1 and main_r.mode == "local":
-            # two pipeline lanes on the card: two detector + enhancer handle pairs, two host threads, detection groups dealt round-robin — the
-            # same frames, crops and seeds as the headline. Their kernels interleave (an HBM-bound 1x1 layer beside an MFMA-bound 3x3 or SR launch,
-            # a 16^2-level layer that fills half the CUs beside anything): more frames/s, but no per-kernel roofline can be read off overlapping launches
-            sec("two_lanes", lanes=2)
-            sec("two_lanes_steps_200", lanes=2, steps=200)
+        if main_r.mode == "local":
+            # pipeline lanes: L detector + enhancer handle pairs, L host threads, detection groups dealt round-robin — the same frames, crops and
+            # seeds whatever L is. Their kernels interleave on the card (an HBM-bound 1x1 layer beside an MFMA-bound 3x3 or SR launch, a 16^2-level
+            # layer that fills half the CUs beside anything). The row is the headline's loop on the OTHER lane count
+            if main_r.n_lanes == 1:
+                sec("two_lanes", lanes=2)
+                sec("two_lanes_steps_200", lanes=2, steps=200)
+            else:
+                sec("one_lane", lanes=1)
+                sec("one_lane_steps_200", lanes=1, steps=200)
         sec("frames_resident_in_hbm", resident=True)
         def sec_fn(name, fn):
             if only and name not in only:
@@ -1007,7 +1048,7 @@ def main():
         roof = None
         pmc = {}
         pmc_src = None
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # HBM bytes per launch from the committed PMC passes, keyed by kernel variant
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # HBM bytes per launch from the committed PMC passes, keyed by kernel variant
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     pmc = json.load(fh).get("kernels", {})
@@ -1022,8 +1063,15 @@ def main():
             kname = "conv_rows16pc_kernel" if d["variant"].endswith("_rows16pc") else "conv_rows16_kernel" if d["variant"].endswith("_rows16") else "conv_rows_kernel" if "_rows" in d["variant"] else "conv_mfma_kernel"
             roof = {"bound": "mfma", "kernel": f"{kname}<{d['variant']}> ({d['stage']})", "achieved": round(ach, 2),
                     "peak": PEAK_TFLOPS[dtp], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtp], 4),
+                    # algorithmic bytes of the SAME launches the events timed: inputs, residuals and outputs once + weights once (ffp_*_profile_bytes)
+                    "algorithmic_bytes": round(d.get("bytes", 0.0) / max(d["launches"], 1)),
+                    # HBM bytes per launch from the committed PMC passes; the same command printed its launches' algorithmic figures (ffp_conv_totals_*),
+                    # so `traffic` and `traffic_population.algorithmic_bytes` are per-launch means over ONE set of launches
                     "traffic": (round(pmc[d["variant"]]["hbm_bytes_per_launch"]) if d["variant"] in pmc else None),
+                    "traffic_population": ({k: pmc[d["variant"]].get(k) for k in ("launches", "algorithmic_bytes_per_launch", "flops_per_launch", "traffic_over_algorithmic",
+                                                                                 "launches_counted_by_the_library")} if d["variant"] in pmc else None),
                     "traffic_source": (f"profiles/{pmc_src} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if d["variant"] in pmc else None),
+                    "events": f"extra profiled pass after the timed region: lane 0 alone, {getattr(main_r, 'profile_steps', 0)} steps, last detection group + last full SR batch",
                     "launches": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2),
                     "flops_per_launch": d["flops"] / max(d["launches"], 1),
                     "sustained_mfma_loop": ({"tflops": SUSTAINED_TFLOPS[dtp], "frac_of_it": round(ach / SUSTAINED_TFLOPS[dtp], 4),
@@ -1039,13 +1087,16 @@ def main():
                        "frames_per_step": B, "det_batch_frames": main_r.DB, "sr_batch_frames": main_r.SB, "mode": main_r.mode,
                        "lanes": main_r.n_lanes,
                        "lanes_note": ("detection groups are dealt round-robin to %d lanes (one detector + enhancer handle pair and one host thread each) whose kernels "
-                                      "interleave on the card; the kernel events behind roofline are taken on the lane that owns the last group, whose final SR batch "
-                                      "waits for the other lanes to finish and runs with the card to itself (inside the timed region); conv_profile_last_step / "
-                                      "stage_ms_last_call are that lane's last detection group WITH another lane's kernels beside it; per_rank stage times are "
-                                      "summed over the lanes' host threads"
+                                      "interleave on the card; the kernel events behind roofline / conv_profile_last_step / stage_ms_last_call come from an extra pass "
+                                      "AFTER the timed region, on lane 0 alone; per_rank stage times are summed over the lanes' host threads"
                                       % main_r.n_lanes) if main_r.n_lanes > 1 else None,
                        "collective": {"backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None, "ranks": world,
-                                      "all_gathers_per_group": int(bool(main_state.get("gathered")))},
+                                      "communicator_ranks": (dist.get_world_size() if world > 1 else 1),
+                                      "all_gathers_per_group": int(bool(main_state.get("gathered"))),
+                                      "exchange_ms_per_step_by_rank": [r_["stage_ms_per_step"].get("exchange", 0.0) for r_ in main_report]},
+                       "hbm_bytes_peak": hbm_peak[0], "hbm_bytes_in_use_after_headline": hbm_headline, "hbm_bytes_headline_handles": main_mem,
+                       "hbm_note": "hbm_bytes_peak: the most bytes in use on the card (hipMemGetInfo: all allocators) at the sampling points — after the headline's timed loop "
+                                   "and at the end of every secondary row; *_handles: packed weights + resident plans of the rows' own handles (ffp_det_mem_bytes / ffp_sr_mem_bytes)",
                        "parallelism": (f"items of {B} frame(s) in {world} contiguous cost-balanced blocks; "
                                        + ("one all-gather per group" if main_state.get("gathered") else "whole frames per rank: no exchange needed")) if world > 1 else "single GPU",
                        "upload_bytes_per_group_per_rank": int(main_state.get("upload_bytes", 0)),
@@ -1072,6 +1123,8 @@ def main():
             pre = torch.cat([d[k, :int(c[k])] for k in range(d.shape[0])], 0).cpu().numpy()
             boxes = main_state.get("boxes_frame0", main_state.get("boxes", np.zeros((0, 4), np.int32)))      # the crops the GPU enhanced for THIS frame (frame 0 of the timed loop)
             res["cpu_baseline"] = cpu_baseline(args, ctx["det_w"], ctx["sr_w"], ctx["host_frames"][0], boxes, pre)
+        if args.conv_totals:
+            res["conv_totals"] = _lib.conv_totals()        # last thing before the line is printed: every launch of the process is in it
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -87,6 +87,11 @@ _SIGS = {
     "ffp_sr_plan_state": (C.c_int, [C.c_void_p, _p(C.c_int32), _p(C.c_int32)]),
     "ffp_det_graph_status": (C.c_int, [C.c_void_p, _p(C.c_int32)]),
     "ffp_sr_set_fused_body": (C.c_int, [C.c_void_p, C.c_int]),
+    "ffp_det_profile_bytes": (C.c_int, [C.c_void_p, C.c_int, _p(C.c_double)]),
+    "ffp_sr_profile_bytes": (C.c_int, [C.c_void_p, C.c_int, _p(C.c_double)]),
+    "ffp_conv_totals_enable": (C.c_int, [C.c_int]),
+    "ffp_conv_totals_count": (C.c_int, [_p(C.c_int32)]),
+    "ffp_conv_totals_get": (C.c_int, [C.c_int, C.c_char_p, C.c_int, _p(C.c_double), _p(C.c_double), _p(C.c_int64)]),
     "ffp_sr_mem_bytes": (C.c_int, [C.c_void_p, _p(C.c_uint64), _p(C.c_uint64), _p(C.c_int32)]),
     "ffp_det_mem_bytes": (C.c_int, [C.c_void_p, _p(C.c_uint64), _p(C.c_uint64), _p(C.c_int32)]),
     "ffp_det_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),
@@ -311,7 +316,7 @@ class Detector:
         _check(lib().ffp_det_set_profile(self._h, int(on)))
 
     def profile(self) -> List[dict]:
-        return _profile(self._h, lib().ffp_det_profile_count, lib().ffp_det_profile_get)
+        return _profile(self._h, lib().ffp_det_profile_count, lib().ffp_det_profile_get, lib().ffp_det_profile_bytes)
 
     def profile_detail(self) -> List[dict]:
         return _profile_detail(self._h, lib().ffp_det_profile_detail)
@@ -333,15 +338,35 @@ def _profile_detail(h, fn) -> List[dict]:
         i += 1
 
 
-def _profile(h, count_fn, get_fn) -> List[dict]:
+def _profile(h, count_fn, get_fn, bytes_fn=None) -> List[dict]:
     n = C.c_int32(0)
     _check(count_fn(h, C.byref(n)))
     out = []
     for i in range(n.value):
         name = C.create_string_buffer(64)
-        fl, ms, ln = C.c_double(0), C.c_float(0), C.c_int32(0)
+        fl, ms, ln, by = C.c_double(0), C.c_float(0), C.c_int32(0), C.c_double(0)
         _check(get_fn(h, i, name, 64, C.byref(fl), C.byref(ms), C.byref(ln)))
-        out.append({"variant": name.value.decode(), "flops": fl.value, "ms": ms.value, "launches": ln.value})
+        if bytes_fn is not None:
+            _check(bytes_fn(h, i, C.byref(by)))
+        out.append({"variant": name.value.decode(), "flops": fl.value, "ms": ms.value, "launches": ln.value, "bytes": by.value})
+    return out
+
+
+def conv_totals_enable(on: bool = True):
+    """Start (and zero) / stop the process-wide per-variant totals of every plan execution (ffp_conv_totals_*)."""
+    _check(lib().ffp_conv_totals_enable(int(on)))
+
+
+def conv_totals() -> dict:
+    """{variant: {"launches", "flops", "bytes"}} since conv_totals_enable(True): algorithmic figures of every launch, graph replays included."""
+    n = C.c_int32(0)
+    _check(lib().ffp_conv_totals_count(C.byref(n)))
+    out = {}
+    for i in range(n.value):
+        name = C.create_string_buffer(64)
+        fl, by, ln = C.c_double(0), C.c_double(0), C.c_int64(0)
+        _check(lib().ffp_conv_totals_get(i, name, 64, C.byref(fl), C.byref(by), C.byref(ln)))
+        out[name.value.decode()] = {"launches": int(ln.value), "flops": fl.value, "bytes": by.value}
     return out
 
 
@@ -448,7 +473,7 @@ class Enhancer:
         _check(lib().ffp_sr_set_profile(self._h, int(on)))
 
     def profile(self) -> List[dict]:
-        return _profile(self._h, lib().ffp_sr_profile_count, lib().ffp_sr_profile_get)
+        return _profile(self._h, lib().ffp_sr_profile_count, lib().ffp_sr_profile_get, lib().ffp_sr_profile_bytes)
 
     def profile_detail(self) -> List[dict]:
         return _profile_detail(self._h, lib().ffp_sr_profile_detail)

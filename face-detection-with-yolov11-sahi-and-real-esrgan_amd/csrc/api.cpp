@@ -308,6 +308,14 @@ static int profile_get(ConvProfile& p, int i, char* name, int cap, double* flops
   return FFP_OK;
 }
 
+static int profile_bytes(ConvProfile& p, int i, double* bytes) {
+  if (i < 0 || i >= (int)p.table.size() || !bytes) return FFP_ERR_ARG;
+  auto it = p.table.begin();
+  std::advance(it, i);
+  *bytes = it->second.bytes;
+  return FFP_OK;
+}
+
 static int detail_get(ConvProfile& p, int i, char* name, int cap, double* flops, float* ms) {
   if (i < 0 || i >= (int)p.detail.size()) return FFP_ERR_ARG;
   if (name && cap > 0) std::snprintf(name, cap, "%s", p.detail[i].variant.c_str());
@@ -506,6 +514,30 @@ int ffp_sr_profile_count(ffp_sr* s, int32_t* n) { if (!s || !n) return FFP_ERR_A
 int ffp_sr_profile_get(ffp_sr* s, int i, char* name, int cap, double* flops, float* ms, int32_t* launches) {
   if (!s) return FFP_ERR_ARG;
   return profile_get(s->eng.prof, i, name, cap, flops, ms, launches);
+}
+
+int ffp_det_profile_bytes(ffp_det* d, int i, double* out_bytes) { return d ? profile_bytes(d->eng.prof, i, out_bytes) : FFP_ERR_ARG; }
+int ffp_sr_profile_bytes(ffp_sr* s, int i, double* out_bytes) { return s ? profile_bytes(s->eng.prof, i, out_bytes) : FFP_ERR_ARG; }
+
+int ffp_conv_totals_enable(int on) {
+  conv_totals_enable(on != 0);
+  return FFP_OK;
+}
+
+int ffp_conv_totals_count(int32_t* out_n) {
+  if (!out_n) return FFP_ERR_ARG;
+  *out_n = (int32_t)conv_totals().size();
+  return FFP_OK;
+}
+
+int ffp_conv_totals_get(int i, char* name, int cap, double* flops, double* bytes, int64_t* launches) {
+  const auto v = conv_totals();
+  if (i < 0 || i >= (int)v.size()) return FFP_ERR_ARG;
+  if (name && cap > 0) std::snprintf(name, cap, "%s", v[i].variant.c_str());
+  if (flops) *flops = v[i].flops;
+  if (bytes) *bytes = v[i].bytes;
+  if (launches) *launches = v[i].launches;
+  return FFP_OK;
 }
 
 // ---- single operator (parity tests) ------------------------------------------------------------------------------------------

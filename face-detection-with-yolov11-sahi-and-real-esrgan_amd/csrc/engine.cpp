@@ -1,6 +1,8 @@
 // engine.cpp — plan bookkeeping and conv-kernel profiling.
 #include "engine.hpp"
 
+#include <mutex>
+
 #include <shared_mutex>
 
 #include <cstdlib>
@@ -29,9 +31,9 @@ int ConvProfile::open(hipStream_t st) {
   return slot;
 }
 
-void ConvProfile::close(int slot, hipStream_t st, const std::string& variant, double flops, const std::string& name) {
+void ConvProfile::close(int slot, hipStream_t st, const std::string& variant, double flops, const std::string& name, double bytes) {
   FFP_HIP(hipEventRecord(ev[slot].second, st));
-  pending.push_back({slot, variant, flops, name});
+  pending.push_back({slot, variant, flops, name, bytes});
 }
 
 void ConvProfile::collect() {
@@ -41,10 +43,11 @@ void ConvProfile::collect() {
     Entry& e = table[p.variant];
     e.variant = p.variant;
     e.flops += p.flops;
+    e.bytes += p.bytes;
     e.ms += ms;
     e.launches += 1;
     Entry d;
-    d.variant = p.variant + " " + p.name; d.flops = p.flops; d.ms = ms; d.launches = 1;
+    d.variant = p.variant + " " + p.name; d.flops = p.flops; d.ms = ms; d.launches = 1; d.bytes = p.bytes;
     detail.push_back(d);
   }
   pending.clear();
@@ -68,6 +71,59 @@ double Step::actual_flops() const {
   double f = 0;
   for (const auto& c : fused) f += conv_flops_of(*c->pc, c->out.lvl->actual_px());
   return f;
+}
+
+static double conv_bytes_of(const ConvOp& c) {
+  const PackedConv& pc = *c.pc;
+  const double opx = (double)c.out.lvl->actual_px(), ipx = (double)c.in.lvl->actual_px();
+  const double ie = (double)dsize(c.in.dt), oe = (double)dsize(c.out.dt);
+  double b = opx * pc.cout * oe;
+  if (c.has_up2) b += (double)c.up2.lvl->actual_px() * c.up2_c * (double)dsize(c.up2.dt) + ipx * (pc.cin_real - c.up2_c) * ie;
+  else b += ipx * pc.cin_real * ie;
+  if (c.has_res1) b += opx * pc.cout * (double)dsize(c.res1.dt);
+  if (c.has_res2) b += opx * pc.cout * (double)dsize(c.res2.dt);
+  b += (double)pc.cout * (pc.cin_real / pc.groups) * pc.k * pc.k * (double)dsize(pc.dt) * (pc.split ? 1.0 : 1.0) + 4.0 * pc.cout;
+  return b;
+}
+
+double Step::actual_bytes() const {
+  if (!is_conv) return 0;
+  if (!trunk) return conv_bytes_of(*conv);
+  double b = 0;
+  for (const auto& c : fused) b += conv_bytes_of(*c);
+  return b;
+}
+
+namespace {
+std::mutex g_totals_mu;
+bool g_totals_on = false;
+std::map<std::string, ConvTotals> g_totals;
+}  // namespace
+
+void conv_totals_enable(bool on) {
+  std::lock_guard<std::mutex> lk(g_totals_mu);
+  g_totals_on = on;
+  if (on) g_totals.clear();
+}
+
+std::vector<ConvTotals> conv_totals() {
+  std::lock_guard<std::mutex> lk(g_totals_mu);
+  std::vector<ConvTotals> v;
+  for (auto& kv : g_totals) v.push_back(kv.second);
+  return v;
+}
+
+static void totals_add(const std::vector<Step>& steps) {
+  std::lock_guard<std::mutex> lk(g_totals_mu);
+  if (!g_totals_on) return;
+  for (const Step& s : steps) {
+    if (s.kind != 0 || !s.is_conv) continue;
+    ConvTotals& t = g_totals[s.variant];
+    t.variant = s.variant;
+    t.flops += s.actual_flops();
+    t.bytes += s.actual_bytes();
+    t.launches += 1;
+  }
 }
 
 double Plan::actual_conv_flops() const {
@@ -257,6 +313,7 @@ void Plan::tune(hipStream_t st) {
 
 void Plan::execute(hipStream_t st, ConvProfile* prof) {
   if (!tuned) tune(st);
+  if (g_totals_on) totals_add(steps);
   const bool p = prof && prof->enabled;
   if (p) {                                   // per-launch events: always eager
     for (Step& s : steps) {
@@ -264,7 +321,7 @@ void Plan::execute(hipStream_t st, ConvProfile* prof) {
       if (s.is_conv) {
         const int slot = prof->open(st);
         s.run(st);
-        prof->close(slot, st, s.variant, s.actual_flops(), s.name);
+        prof->close(slot, st, s.variant, s.actual_flops(), s.name, s.actual_bytes());
       } else {
         s.run(st);
       }

@@ -12,17 +12,17 @@ namespace ffp {
 
 // Per-launch HIP-event timing of convolution kernels, aggregated by kernel variant ("f32 k3s1 wide", ...).
 struct ConvProfile {
-  struct Entry { std::string variant; double flops = 0; double ms = 0; int launches = 0; };
+  struct Entry { std::string variant; double flops = 0; double ms = 0; int launches = 0; double bytes = 0; };
   bool enabled = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // recycled pool
-  struct Pending { int ev; std::string variant; double flops; std::string name; };
+  struct Pending { int ev; std::string variant; double flops; std::string name; double bytes; };
   std::vector<Entry> detail;                      // one entry per launch of the last call (variant = "<variant> <layer name>")
   std::vector<Pending> pending;
   std::map<std::string, Entry> table;
   ~ConvProfile();
   void begin();                                  // clear the table, start collecting
   int open(hipStream_t st);                      // record a start event, returns slot
-  void close(int slot, hipStream_t st, const std::string& variant, double flops, const std::string& name);
+  void close(int slot, hipStream_t st, const std::string& variant, double flops, const std::string& name, double bytes = 0);
   void collect();                                // after the stream has drained
 };
 
@@ -37,6 +37,9 @@ struct Step {
   std::shared_ptr<TrunkPlan> trunk;
   std::vector<std::shared_ptr<ConvOp>> fused;
   double actual_flops() const;       // algorithmic FLOPs of the batch the step's level currently describes
+  // algorithmic bytes of the same batch: every input, residual and output element once (the real channels at the tensors' element size) plus the
+  // weights and the bias once — what a launch must move if nothing is read twice; the PMC traffic of the launch is compared with this
+  double actual_bytes() const;
   std::string variant, name;
   double flops = 0;
   // lanes: steps of different lanes have no data dependency between a fork and the matching join and may overlap on the device
@@ -119,6 +122,13 @@ struct CaptureExclusive {
   CaptureExclusive();
   ~CaptureExclusive();
 };
+
+// Lifetime totals per kernel variant over every plan execution of the process (eager, profiled or graph replay): launches, algorithmic FLOPs
+// and algorithmic bytes. Off by default (a map walk per execution); bench.py switches it on for the run a PMC pass measures, so that the
+// counters' per-launch traffic and the per-launch algorithmic figures describe ONE population of launches (ffp_conv_totals_*).
+struct ConvTotals { std::string variant; double flops = 0, bytes = 0; long long launches = 0; };
+void conv_totals_enable(bool on);
+std::vector<ConvTotals> conv_totals();
 
 inline double conv_flops_of(const PackedConv& pc, int64_t out_px) {
   return 2.0 * (double)(pc.cin_real / pc.groups) * pc.k * pc.k * (double)pc.cout * (double)out_px;

@@ -332,6 +332,17 @@ int ffp_det_profile_get(ffp_det* d, int i, char* name, int name_cap, double* out
 int ffp_sr_set_profile(ffp_sr* s, int enable);
 int ffp_sr_profile_count(ffp_sr* s, int32_t* out_n);
 int ffp_sr_profile_get(ffp_sr* s, int i, char* name, int name_cap, double* out_flops, float* out_ms, int32_t* out_launches);
+/* algorithmic bytes of entry i of the same table: every input, residual and output element of the launches once (real channels, the tensors'
+ * element size) + weights and bias once — the denominator for the PMC traffic of the same launches (bench.py: roofline.algorithmic_bytes) */
+int ffp_det_profile_bytes(ffp_det* d, int i, double* out_bytes);
+int ffp_sr_profile_bytes(ffp_sr* s, int i, double* out_bytes);
+/* Process-wide lifetime totals per kernel variant over EVERY plan execution since enable(1) (eager, profiled or hipGraph replay; all handles):
+ * launches, algorithmic FLOPs, algorithmic bytes. A rocprofv3 --pmc pass over a command sums its counters over all launches of a kernel; with
+ * these totals printed by the same command (bench.py --conv-totals), traffic per launch and algorithmic bytes per launch describe one population.
+ * Off by default. Diagnostics only: the reference has no counterpart (its torch modules are opaque to it). */
+int ffp_conv_totals_enable(int on);
+int ffp_conv_totals_count(int32_t* out_n);
+int ffp_conv_totals_get(int i, char* name, int name_cap, double* out_flops, double* out_bytes, int64_t* out_launches);
 /* per-launch entries of the last profiled call, in launch order: "<variant> <layer name>"; returns FFP_ERR_ARG past the end */
 int ffp_det_profile_detail(ffp_det* d, int i, char* name, int name_cap, double* out_flops, float* out_ms);
 int ffp_sr_profile_detail(ffp_sr* s, int i, char* name, int name_cap, double* out_flops, float* out_ms);

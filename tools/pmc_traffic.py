@@ -80,6 +80,27 @@ def main():
         wr = (w[v][1] / w[v][0] * 1024) if v in w and w[v][0] else 0.0
         out["kernels"][v] = {"launches": n, "avg_us": t / n, "hbm_fetch_bytes_per_launch_x2corrected": fetch, "hbm_write_bytes_per_launch": wr,
                              "symbol": sym, "hbm_bytes_per_launch": fetch + wr}
+    # argv[4]: stdout of the SAME command under the FETCH pass, run with --conv-totals: the library's own count of every conv launch of that process and
+    # its algorithmic FLOPs / bytes -> per-launch means over the same launches the counters summed (one population for traffic / algorithmic bytes)
+    if len(sys.argv) > 4:
+        tot = {}
+        try:
+            with open(sys.argv[4]) as fh:
+                for line in fh:
+                    line = line.strip()
+                    if line.startswith("{") and "conv_totals" in line:
+                        tot = json.loads(line).get("conv_totals", {})
+        except Exception as e:      # noqa: BLE001
+            print("no conv_totals:", e)
+        out["_population"] = ("algorithmic_bytes_per_launch / flops_per_launch: ffp_conv_totals_* printed by the profiled command itself (bench.py --conv-totals) — every "
+                              "launch of the process, hipGraph replays included; launches_counted_by_the_library should equal launches (the counters' own launch count)")
+        for v, k in out["kernels"].items():
+            t = tot.get(v)
+            if t and t["launches"]:
+                k["launches_counted_by_the_library"] = t["launches"]
+                k["algorithmic_bytes_per_launch"] = t["bytes"] / t["launches"]
+                k["flops_per_launch"] = t["flops"] / t["launches"]
+                k["traffic_over_algorithmic"] = round(k["hbm_bytes_per_launch"] / max(k["algorithmic_bytes_per_launch"], 1.0), 3)
     path = os.path.join(ROOT, "profiles", (sys.argv[3] if len(sys.argv) > 3 else "r02") + "_pmc_traffic.json")
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
