@@ -935,7 +935,7 @@ def main():
     # ---- secondary rows, measured in this same run (--secondary-steps, default 20 like the headline): what the headline configuration is NOT ------------------------
     secondary = {}
     if not args.no_secondary:
-        ss, sw = max(2, args.secondary_steps), max(2, min(args.warmup, 4))
+        ss, sw = max(2, args.secondary_steps), max(2, min(args.warmup, main_r.DB))     # whole detection groups: a warm-up of 4 would lay out a 4-frame plan beside the 5-frame one
 
         only = set(x for x in args.secondary_only.split(",") if x)
 
@@ -962,6 +962,13 @@ def main():
                                                                                      np.concatenate([hf[(i + 1) % len(hf)], hf[i]], 1)], 0)) for i in range(len(hf))]
                     if wl.get("sr_crops", args.sr_crops) > 0 and ctx_r["sr_w"] is None:
                         ctx_r["sr_w"] = synth.rrdbnet_weights(4, 23)
+                if share is None or kw.get("det_precision") or kw.get("imgsz"):
+                    # a row with handles or plans of its own: the headline handles give their plans back first (rebuilt, untimed, by the next row
+                    # that shares them) — four ranks on one card, or the 4x-larger plans of image_size 1024, fit beside nothing else
+                    for p_ in {id(q): q for q in pipes}.values():
+                        p_.det.drop_plans()
+                        if p_.sr is not None:
+                            p_.sr.drop_plans()
                 r = Runner(args, ctx_r, pipes=share, **kw)
                 d = r.timed(sw, steps_r, profile_last=prof_sr)
                 rep = r.report(steps_r)
@@ -984,12 +991,14 @@ def main():
             finally:
                 if r is not None:
                     r.close()                          # a row's own handles, slots and pinned buffers go before the next row is built
+                if rank == 0:
+                    print(f"[bench] row {name}: {secondary.get(name, {}).get('value')}", file=sys.stderr, flush=True)
             return r
 
         # the reference's own order: strictly one frame, one SR pass at a time (docs sahi/predict.py:226,270) — nothing batched across frames
         sec("frame_by_frame", det_batch=1, sr_batch=1, profile_sr=True, lanes=1)      # one lane: never two frames on the card at once
         sec("steps_200", steps=200)                       # the headline configuration over a 10x longer timed region
-        if main_r.mode == "local":
+        if main_r.mode == "local" and world == 1:
             # pipeline lanes: L detector + enhancer handle pairs, L host threads, detection groups dealt round-robin — the same frames, crops and
             # seeds whatever L is. Their kernels interleave on the card (an HBM-bound 1x1 layer beside an MFMA-bound 3x3 or SR launch, a 16^2-level
             # layer that fills half the CUs beside anything). The row is the headline's loop on the OTHER lane count
@@ -1127,8 +1136,11 @@ def main():
             res["conv_totals"] = _lib.conv_totals()        # last thing before the line is printed: every launch of the process is in it
         print(json.dumps(res), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:                                        # a secondary row that failed on some ranks only (out of memory on a shared card) leaves the
+            dist.barrier()                          # ranks out of step; the line is printed by then, and the run must still end
+            dist.destroy_process_group()
+        except Exception as e:      # noqa: BLE001
+            print(f"[bench] rank {rank}: final barrier: {type(e).__name__}", file=sys.stderr, flush=True)
 
 
 if __name__ == "__main__":

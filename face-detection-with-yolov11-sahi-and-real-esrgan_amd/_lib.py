@@ -87,6 +87,8 @@ _SIGS = {
     "ffp_sr_plan_state": (C.c_int, [C.c_void_p, _p(C.c_int32), _p(C.c_int32)]),
     "ffp_det_graph_status": (C.c_int, [C.c_void_p, _p(C.c_int32)]),
     "ffp_sr_set_fused_body": (C.c_int, [C.c_void_p, C.c_int]),
+    "ffp_det_drop_plans": (C.c_int, [C.c_void_p]),
+    "ffp_sr_drop_plans": (C.c_int, [C.c_void_p]),
     "ffp_det_profile_bytes": (C.c_int, [C.c_void_p, C.c_int, _p(C.c_double)]),
     "ffp_sr_profile_bytes": (C.c_int, [C.c_void_p, C.c_int, _p(C.c_double)]),
     "ffp_conv_totals_enable": (C.c_int, [C.c_int]),
@@ -304,6 +306,10 @@ class Detector:
         _check(lib().ffp_det_mem_bytes(self._h, C.byref(a), C.byref(b), C.byref(n)))
         return {"weights": int(a.value), "plans": int(b.value), "plans_resident": int(n.value)}
 
+    def drop_plans(self):
+        """Release every resident plan now (rebuilt on demand); the packed weights stay."""
+        _check(lib().ffp_det_drop_plans(self._h))
+
     def set_lanes(self, mode: int):
         """0 (default) one stream; 1 head towers and C3k side convs as parallel graph branches (detector-only deployments)."""
         _check(lib().ffp_det_set_lanes(self._h, int(mode)))
@@ -461,6 +467,10 @@ class Enhancer:
         a, b, n = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
         _check(lib().ffp_sr_mem_bytes(self._h, C.byref(a), C.byref(b), C.byref(n)))
         return {"weights": int(a.value), "plans": int(b.value), "plans_resident": int(n.value)}
+
+    def drop_plans(self):
+        """Release every resident plan now (rebuilt on demand); the packed weights stay."""
+        _check(lib().ffp_sr_drop_plans(self._h))
 
     def plan_state(self) -> dict:
         """plans_built: network layouts built so far (capacity-keyed: varying crop sizes must not grow it);

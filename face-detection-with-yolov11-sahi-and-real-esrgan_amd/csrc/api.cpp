@@ -501,6 +501,20 @@ int ffp_det_mem_bytes(ffp_det* d, uint64_t* out_weight_bytes, uint64_t* out_plan
   return FFP_OK;
 }
 
+int ffp_det_drop_plans(ffp_det* d) {
+  FFP_API_BEGIN
+  FFP_CHECK(d, FFP_ERR_ARG, "null handle");
+  d->eng.drop_plans();
+  FFP_API_END
+}
+
+int ffp_sr_drop_plans(ffp_sr* s) {
+  FFP_API_BEGIN
+  FFP_CHECK(s, FFP_ERR_ARG, "null handle");
+  s->eng.drop_plans();
+  FFP_API_END
+}
+
 int ffp_sr_last_ms(ffp_sr* s, float* out_ms) { if (!s || !out_ms) return FFP_ERR_ARG; *out_ms = s->eng.last_ms; return FFP_OK; }
 int ffp_sr_last_conv_stats(ffp_sr* s, double* out_flops, float* out_ms, int32_t* out_launches) {
   if (!s) return FFP_ERR_ARG;

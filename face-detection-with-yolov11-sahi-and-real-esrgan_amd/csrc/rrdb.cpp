@@ -47,6 +47,13 @@ void SrEngine::set_fused_body(bool on) {
   fused_body_ = on;
 }
 
+void SrEngine::drop_plans() {
+  FFP_HIP(hipSetDevice(device_));
+  if (pending_) wait_done();
+  FFP_HIP(hipStreamSynchronize(st_));
+  plans_.clear();
+}
+
 size_t SrEngine::plan_bytes() const {
   size_t b = 0;
   for (const auto& kv : plans_) b += kv.second->bytes;

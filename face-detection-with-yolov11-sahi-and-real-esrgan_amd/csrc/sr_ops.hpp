@@ -61,6 +61,7 @@ class SrEngine {
   // results either way. Default: fused in fp16 unless FFP_TRUNK=0. Changing it drops the resident plans.
   void set_fused_body(bool on);
   bool fused_body() const { return fused_body_; }
+  void drop_plans();            // release every resident plan (waits for the batch in flight and the stream first)
   size_t plan_bytes() const;    // device memory held by the resident plans (activations, tables), without the packed weights
   size_t weight_bytes() const { return weight_bytes_; }
   int plans_resident() const { return (int)plans_.size(); }

@@ -389,6 +389,12 @@ DetPlan* DetEngine::plan_for(const std::vector<TileGeom>& g) {
   return it->second.get();
 }
 
+void DetEngine::drop_plans() {
+  FFP_HIP(hipSetDevice(device_));
+  FFP_HIP(hipStreamSynchronize(st_));
+  plans_.clear();
+}
+
 size_t DetEngine::plan_bytes() const {
   size_t b = 0;
   for (const auto& kv : plans_) b += kv.second->bytes;

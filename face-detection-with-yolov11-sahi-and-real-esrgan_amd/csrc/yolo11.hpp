@@ -41,6 +41,7 @@ class DetEngine {
   // device memory: resident plans (activations + tables; one plan per batch shape, least recently used ones are dropped beyond 8 plans or
   // beyond the byte budget — env FFP_DET_PLAN_GIB, default 64) and the packed weights
   size_t plan_bytes() const;
+  void drop_plans();            // release every resident plan (the next call lays its plan out again); waits for the stream first
   size_t weight_bytes() const { return weight_bytes_; }
   int plans_resident() const { return (int)plans_.size(); }
 

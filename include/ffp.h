@@ -211,6 +211,10 @@ int ffp_sr_set_fused_body(ffp_sr* s, int on);
  * reference holds one torch module per model (utils/yolo_wrapper.py:47-61, utils/enhancer.py:156) and lets torch's caching
  * allocator grow; here a caller that switches image_size or batch shapes can see — and bound — what stays resident. */
 int ffp_sr_mem_bytes(ffp_sr* s, uint64_t* out_weight_bytes, uint64_t* out_plan_bytes, int32_t* out_plans_resident);
+/* Release every resident plan of a handle now (activations, tables, captured graphs; the packed weights stay). The next call lays its plan out
+ * again (tens of ms: layout, tuning, graph capture). The counterpart of `del model; torch.cuda.empty_cache()` around the reference's modules. */
+int ffp_det_drop_plans(ffp_det* d);
+int ffp_sr_drop_plans(ffp_sr* s);
 int ffp_det_mem_bytes(ffp_det* d, uint64_t* out_weight_bytes, uint64_t* out_plan_bytes, int32_t* out_plans_resident);
 /* hipGraph state of the plan the detector's last call ran: 1 replayed a captured graph, 0 not captured yet (first runs of a
  * plan are eager), -1 capture failed and the plan keeps launching eagerly (also reported once on stderr). */
