@@ -76,6 +76,8 @@ VARIANTS = {
     "r16_stash2": (["conv_rows16.hip"], ["-DFFP_R16_STASH=2"]),
     "k3d_dbg": (["conv_k3d.hip"], ["-DFFP_K3D_DBG=1"]),
     "trunk_dbg": (["conv_trunk.hip"], ["-DFFP_TRUNK_DBG=1"]),               # s_memtime stamps per phase of the fused-body kernel (tools/trunk_stamp_probe.py)
+    "trunk_dbg_w5": (["conv_trunk.hip"], ["-DFFP_TRUNK_DBG=1", "-DFFP_TRUNK_STAMP_WAVE=5"]),      # stamps of a pixel loader (wave 5) instead of the control wave
+    "trunk_dbg_w11": (["conv_trunk.hip"], ["-DFFP_TRUNK_DBG=1", "-DFFP_TRUNK_STAMP_WAVE=11"]),
     "trunk_dbg_skip18": (["conv_trunk.hip"], ["-DFFP_TRUNK_DBG=1", "-DFFP_TRUNK_SKIP=18"]),   # stamps without MFMAs and fragment reads: is the end-of-step wait the DMA itself?
     "trunk_dbg_skip4": (["conv_trunk.hip"], ["-DFFP_TRUNK_DBG=1", "-DFFP_TRUNK_SKIP=4"]),     # stamps without DMA
     "trunk_dbg_skip16": (["conv_trunk.hip"], ["-DFFP_TRUNK_DBG=1", "-DFFP_TRUNK_SKIP=16"]),   # stamps without fragment reads

@@ -556,8 +556,11 @@ __global__ void __launch_bounds__(768, 3) conv_trunk_kernel(const TrunkArgs a) {
   unsigned long long tsum[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();      // top + control, set-up, step (MFMAs / DMA issue), epilogue + next item, wait, barrier, synchronous staging
   unsigned n_iter = 0, n_slow = 0;
 #define TSTAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsum[k] += t_ - tprev; tprev = t_; }
-#define TDUMP() if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) { unsigned* o = a.queue + 2 + (wave >> 2) * 7; for (int k_ = 0; k_ < 7; ++k_) o[k_] = (unsigned)(tsum[k_] / (n_iter ? n_iter : 1)); \
-                  if (wave == 4) { o[6] = n_iter | (n_slow << 16); } }
+#ifndef FFP_TRUNK_STAMP_WAVE
+#define FFP_TRUNK_STAMP_WAVE 4       // which loader wave's sums are printed beside compute wave 0's (4 = loader 0, the control wave; 5..11 stage pixel pieces)
+#endif
+#define TDUMP() if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == FFP_TRUNK_STAMP_WAVE)) { unsigned* o = a.queue + 2 + (wave ? 1 : 0) * 7; for (int k_ = 0; k_ < 7; ++k_) o[k_] = (unsigned)(tsum[k_] / (n_iter ? n_iter : 1)); \
+                  if (wave) { o[6] = n_iter | (n_slow << 16); } }
 #else
 #define TSTAMP(k)
 #define TDUMP()
