@@ -1168,6 +1168,8 @@ void launch_conv(const ConvOp& op, hipStream_t st) {
   FFP_HIP(hipGetLastError());
 }
 
+std::string conv_variant(const ConvOp& op);
+
 int conv_tune(const ConvOp& op, hipStream_t st) {
   const PackedConv& pc = *op.pc;
   if (conv_direct_eligible(op)) return -1;
@@ -1201,6 +1203,13 @@ int conv_tune(const ConvOp& op, hipStream_t st) {
     const float t = time_shape(shape, iters);
     if (shape == heur) heur_t = t;
     if (best < 0 || t < best_t) { best = shape; best_t = t; }
+    static const bool log = [] { const char* e = getenv("FFP_TUNE_LOG"); return e && e[0] == '1'; }();       // every candidate's time, one line per (layer, shape)
+    if (log) {
+      ConvOp o = op;
+      o.force_shape = shape;
+      fprintf(stderr, "[tune] %-28s %4d->%4d k%d s%d px %9lld  shape %2d %-22s %9.1f us%s\n", pc.name.c_str(), pc.cin_real, pc.cout, pc.k, op.stride,
+              (long long)op.out.lvl->actual_px(), shape, conv_variant(o).c_str(), t, shape == heur ? "  (heuristic)" : "");
+    }
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
