@@ -1043,7 +1043,7 @@ def main():
                 r = sec("one_frame_across_ranks", frames_per_step=1, exchange="auto")
                 secondary["one_frame_across_ranks"]["scaling"] = "strong"        # (key exists whether or not the row failed)
         if args.sr_crops > 0 and world == 1:
-            r = sec("with_jpeg_decode_and_encode", jpeg_io=True)
+            r = sec("with_jpeg_decode_and_encode", jpeg_io=True, lanes=1)     # one lane: two lanes' decode pools (8 host threads each) and codec calls get in each other's way (110 vs 125-128 frames/s)
             if r is not None and secondary["with_jpeg_decode_and_encode"].get("value") is not None:
               secondary["with_jpeg_decode_and_encode"].update({"note": "frames arrive as JPEG (quality 95, 4:2:0) and are decoded into device memory; enhanced crops leave as JPEG files "
                                                                      "(quality 95, byte-identical to cv2.imwrite); reported separately as SURVEY §8(d) prescribes",
