@@ -216,3 +216,34 @@ const int* Level::up2_map(const Level* src, hipStream_t st) {
 }
 
 }  // namespace ffp
+
+
+namespace ffp {
+
+hipStream_t create_engine_stream(const char* env_name) {
+  hipStream_t st = nullptr;
+  const char* e = env_name ? getenv(env_name) : nullptr;
+  int lo = 0, hi = 0;
+  if (e && sscanf(e, "%d-%d", &lo, &hi) == 2 && lo >= 0 && hi > lo && hi <= 32) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    FFP_HIP(hipGetDevice(&dev));
+    FFP_HIP(hipGetDeviceProperties(&prop, dev));
+    const int ncu = prop.multiProcessorCount;                 // 256 on MI355X: 8 XCDs x 32 CUs
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    // bit i of the mask = CU i in the runtime's enumeration; both plausible enumerations (XCD-major, CU-major) are covered by setting the
+    // range in every group of 32 AND the matching interleaved positions is not possible at once: FFP_CU_MASK_ORDER=1 selects CU-major
+    const char* ord = getenv("FFP_CU_MASK_ORDER");
+    const bool cu_major = ord && ord[0] == '1';
+    for (int i = 0; i < ncu; ++i) {
+      const int cu_in_xcd = cu_major ? i / 8 : i % 32;
+      if (cu_in_xcd >= lo && cu_in_xcd < hi) mask[i / 32] |= 1u << (i % 32);
+    }
+    FFP_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    return st;
+  }
+  FFP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  return st;
+}
+
+}  // namespace ffp

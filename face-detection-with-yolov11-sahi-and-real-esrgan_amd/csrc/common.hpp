@@ -17,6 +17,11 @@
 
 namespace ffp {
 
+// An engine's stream. env `name` (FFP_DET_CU_MASK / FFP_SR_CU_MASK, experiment): "lo-hi" = only CUs lo..hi-1 of EVERY XCD run this stream's
+// kernels (hipExtStreamCreateWithCUMask) — a spatial split of the card between the detector and the enhancer.
+hipStream_t create_engine_stream(const char* env_name);
+
+
 // ---- errors ---------------------------------------------------------------------------------------------
 struct Error : std::runtime_error {
   int code;

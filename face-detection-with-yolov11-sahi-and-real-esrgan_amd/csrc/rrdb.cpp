@@ -19,7 +19,7 @@ SrEngine::SrEngine(const void* weights, size_t nbytes, int scale, int num_block,
   FFP_CHECK(device >= 0 && device < ndev, FFP_ERR_ARG, "device %d of %d", device, ndev);
   scale_ = scale; num_block_ = num_block; device_ = device; dt_ = half ? F16 : F32;
   FFP_HIP(hipSetDevice(device_));
-  FFP_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  st_ = create_engine_stream("FFP_SR_CU_MASK");
   for (auto& e : ev_) FFP_HIP(hipEventCreate(&e));
   conv_kernels_init();
   WeightFile wf;

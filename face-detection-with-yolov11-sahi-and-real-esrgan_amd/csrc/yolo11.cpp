@@ -38,7 +38,7 @@ DetEngine::DetEngine(const void* weights, size_t nbytes, int arch, int nc, int n
   device_ = device; nc_ = nc; nkpt_ = nkpt; scale_ = (char)arch; dt_ = precision == FFP_PREC_F16 ? F16 : F32;
   split_ = precision == FFP_PREC_F32X3;
   FFP_HIP(hipSetDevice(device_));
-  FFP_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  st_ = create_engine_stream("FFP_DET_CU_MASK");
   for (auto& e : ev_) FFP_HIP(hipEventCreate(&e));
   conv_kernels_init();
   WeightFile wf;

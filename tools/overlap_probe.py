@@ -29,6 +29,7 @@ def wall(fns):
     for t in th: t.join()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / N * 1e3
-a, b = wall([det]), wall([sr])
+only_both = os.environ.get("ONLY_BOTH") == "1"        # for a kernel trace: nothing but the concurrent phase after the warm-up
+a, b = (0.0, 0.0) if only_both else (wall([det]), wall([sr]))
 c = wall([det, sr])
 print(f"frames per detect call {NF}, crops per SR call {NC}: detect alone {a:.2f} ms, SR alone {b:.2f} ms (device {pipe.sr.last_ms():.2f}), both at once {c:.2f} ms per pair  (sum {a + b:.2f}, max {max(a, b):.2f})", flush=True)
