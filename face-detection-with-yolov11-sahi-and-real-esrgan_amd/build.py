@@ -74,6 +74,9 @@ VARIANTS = {
     "r16_dbg": (["conv_rows16.hip"], ["-DFFP_R16_DBG=1"]),                  # compile-time phase-skip instantiations (tools/rows16_phase_probe.py)
     "r16_stash1": (["conv_rows16.hip"], ["-DFFP_R16_STASH=1"]),             # staging placement experiments (tools/rows16_stash_probe.sh)
     "r16_stash2": (["conv_rows16.hip"], ["-DFFP_R16_STASH=2"]),
+    "r16_st16": (["conv_rows16.hip"], ["-DFFP_R16_STORE_AUX=16"]),          # output stores write-through (sc1) / sc0 sc1 / nt: is the kernel-end L2 write-back what a launch boundary costs?
+    "r16_st17": (["conv_rows16.hip"], ["-DFFP_R16_STORE_AUX=17"]),
+    "r16_st2": (["conv_rows16.hip"], ["-DFFP_R16_STORE_AUX=2"]),
     "k3d_dbg": (["conv_k3d.hip"], ["-DFFP_K3D_DBG=1"]),
     "trunk_dbg": (["conv_trunk.hip"], ["-DFFP_TRUNK_DBG=1"]),               # s_memtime stamps per phase of the fused-body kernel (tools/trunk_stamp_probe.py)
     "trunk_dbg_w5": (["conv_trunk.hip"], ["-DFFP_TRUNK_DBG=1", "-DFFP_TRUNK_STAMP_WAVE=5"]),      # stamps of a pixel loader (wave 5) instead of the control wave

@@ -35,6 +35,9 @@
 #ifndef FFP_R16_STASH
 #define FFP_R16_STASH 0        // experiment: 1 = the next chunk's ten pieces are written to LDS and re-requested BEFORE the chunk's MFMA stream, 2 = AFTER it
 #endif                         //             (0: one piece per MFMA step, the shipped schedule)
+#ifndef FFP_R16_STORE_AUX
+#define FFP_R16_STORE_AUX 0   // cache policy of the output stores (experiment): 16 = sc1 (write-through: nothing dirty left in L2 for the kernel-end write-back), 17 = sc0 sc1, 2 = nt
+#endif
 #ifndef FFP_R16_STAMP
 #define FFP_R16_STAMP 0        // 1: diagnostic build — s_memtime stamps around the phases of every chunk, sums printed by the first workgroups
 #endif                         //    (MI355X guide, "In-kernel stamps"); never in a shipped build, the stamps cost ~10 % of the kernel
@@ -354,7 +357,7 @@ __global__ void __launch_bounds__(256, (RES ? 1 : 2)) conv_rows16_kernel(const C
       union { u32x4 u; _Float16 h[8]; } ov;
 #pragma unroll
       for (int q = 0; q < 8; ++q) ov.h[q] = (_Float16)v[q];
-      __builtin_amdgcn_raw_buffer_store_b128(ov.u, rs_o, ok ? (rel_px * a.out_cs + ch0) * 2 : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ov.u, rs_o, ok ? (rel_px * a.out_cs + ch0) * 2 : OOB, 0, FFP_R16_STORE_AUX);
     }
   };
 
