@@ -1030,7 +1030,7 @@ def main():
         if world == 1:
             # the other BASELINE configs on the final tree (config 3 is the headline; 4 and the 8-GPU part of 5 need the driver's node)
             sec("config2_detect_only", workload={"sr_crops": 0})           # single 4K image, YOLO11s, SAHI 512 / 0.2, no SR
-            sec("config5_8k_640_one_gpu", workload={"height": 2 * H, "width": 2 * W, "slice": 640, "overlap": 0.25, "imgsz": 640, "sr_crops": 128},
+            sec("config5_8k_640", workload={"height": 2 * H, "width": 2 * W, "slice": 640, "overlap": 0.25, "imgsz": 640, "sr_crops": 128},
                 imgsz=640, det_batch=2, sr_batch=2, steps=min(ss, 8), lanes=1)   # 8K frame, 640 / 0.25 (144 slices + full frame), x4 SR on 128 crops: the one-GPU shape of config 5
         if args.sr_crops > 0 and args.sr_sizes != "fixed":
             sec("sr_sizes_fixed", sr_sizes="fixed")
