@@ -800,6 +800,38 @@ def compat_api_row(args, ctx, steps):
             dt = time.perf_counter() - t0
             return steps / dt, {key: round(v / steps * 1e3, 3) for key, v in tm.items()}
 
+        def file_flow(srcs, n):
+            """pipeline_v1_detection_first/app_v1.py:52-104 on files, literally: sliced prediction on the .jpg, keypoints attached, every detected face saved as a crop
+            file (save_face_crops), the crop directory enhanced (enhance_face_crops_batch: one ragged GPU batch inside) and written back as files."""
+            import shutil
+            from utils.visualization import save_face_crops
+            from utils.enhancer import enhance_face_crops_batch
+            td2 = tempfile.mkdtemp()
+            ncrops = 0
+            try:
+                def once(k):
+                    nonlocal ncrops
+                    src = srcs[k % len(srcs)]
+                    d = os.path.join(td2, f"crops{k}")
+                    with contextlib.redirect_stdout(quiet):
+                        res = get_sliced_prediction(src, model, slice_height=args.slice, slice_width=args.slice, overlap_height_ratio=args.overlap, overlap_width_ratio=args.overlap, verbose=0)
+                        model.attach_keypoints_to_predictions(res.object_prediction_list)
+                        saved = save_face_crops(src, res, d, prefix="f") if res.object_prediction_list else []
+                        if saved and enh is not None:
+                            out = enhance_face_crops_batch(crops_dir=d, enhancer=enh, prefix="f")
+                            assert out["statistics"]["successful"] + out["statistics"]["failed"] == len(saved)
+                    ncrops += len(saved)
+                    shutil.rmtree(d, ignore_errors=True)
+                    shutil.rmtree(os.path.join(td2, "f_enhanced"), ignore_errors=True)
+                once(0); once(1)
+                ncrops = 0
+                t0 = time.perf_counter()
+                for k in range(n):
+                    once(k)
+                return n / (time.perf_counter() - t0), ncrops / n
+            finally:
+                shutil.rmtree(td2, ignore_errors=True)
+
         fps_mem, st_mem = timed(hf)
         state["batched"] = True
         fps_bat, st_bat = timed(hf) if enh is not None else (None, None)
@@ -811,6 +843,7 @@ def compat_api_row(args, ctx, steps):
                 with open(paths[-1], "wb") as fh:
                     fh.write(_lib.jpeg_encode(f, 95, bgr=False))
             fps_jpg, st_jpg = timed(paths)
+            fps_files, crops_files = file_flow(paths, steps)
         return {"value": round(fps_mem, 3), "unit": "frames/s", "steps": steps, "frames": "ndarray in host memory", "host_stage_ms_per_frame": st_mem,
                 "from_jpg_files": {"value": round(fps_jpg, 3), "unit": "frames/s", "host_stage_ms_per_frame": st_jpg},
                 "crops_as_one_batch": ({"value": round(fps_bat, 3), "unit": "frames/s", "host_stage_ms_per_frame": st_bat,
@@ -818,6 +851,9 @@ def compat_api_row(args, ctx, steps):
                                                 "batch instead of one synchronous enhance_image per crop"} if fps_bat else None),
                 "note": "enhance_image is synchronous per crop by signature (it returns the pixels): 32 crops = 32 dependent passes through 349 conv launches, "
                         "about 3 ms each however small the crop; the detection half runs at the frame_by_frame rate",
+                "app_v1_file_flow": {"value": round(fps_files, 3), "unit": "frames/s", "crops_per_frame": round(crops_files, 1),
+                                     "calls": "get_sliced_prediction(.jpg) + attach_keypoints_to_predictions + save_face_crops + enhance_face_crops_batch (pipeline_v1_detection_first/app_v1.py:52-104): "
+                                              "every DETECTED face is cropped, written, enhanced and written again — the crop count is what the random-init detector finds, not the 32-crop law"},
                 "detections_last_frame": state.get("detections"),
                 "calls": "sahi.predict.get_sliced_prediction + utils.enhancer.FaceEnhancer.enhance_image per crop (compat/), one frame and one crop at a time"}
     finally:
