@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def variant(sym: str):
+    if "conv_trunk_kernel" in sym:
+        return "f16_k3s1_trunk"
     if "conv_rows16pc_kernel" in sym:
         return "f16_k3s1_rows16pc"
     if "conv_rows16_kernel" in sym:
