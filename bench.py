@@ -1062,6 +1062,9 @@ def main():
             fb, ca = secondary.get("frame_by_frame", {}).get("value"), secondary.get("through_compat_api", {}).get("value")
             if fb and ca:
                 secondary["through_compat_api"]["vs_frame_by_frame"] = round(ca / fb, 3)
+                cb = (secondary["through_compat_api"].get("crops_as_one_batch") or {}).get("value")
+                if cb:
+                    secondary["through_compat_api"]["crops_as_one_batch"]["vs_frame_by_frame"] = round(cb / fb, 3)
             sec_fn("config1_640_yolo11n", lambda: config1_row(args, ctx))
         if world == 1:
             # the other BASELINE configs on the final tree (config 3 is the headline; 4 and the 8-GPU part of 5 need the driver's node)
