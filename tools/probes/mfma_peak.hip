@@ -8,6 +8,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // MODE 0: 16x16x32 f16, operands in registers; 1: 32x32x16 f16, registers; 2: 16x16x32 with LDS reads per MFMA (RD16 sixteenths of a
 // ds_read_b128 per MFMA); 3: 32x32x16 with LDS reads
@@ -33,7 +34,13 @@ __global__ void __launch_bounds__(256, 2) peak_kernel(const uint4* __restrict__ 
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   unsigned off = lane * 16;
   for (int it = 0; it < iters; ++it) {
-    if constexpr (MODE == 0 || MODE == 2) {
+    if constexpr (MODE == 4) {                    // the CDNA3 form, K = 16: is it still full rate per FLOP on gfx950?
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f16x4 a4 = {a[i & 3].h[0], a[i & 3].h[1], a[i & 3].h[2], a[i & 3].h[3]}, b4 = {b[(i >> 2) & 3].h[0], b[(i >> 2) & 3].h[1], b[(i >> 2) & 3].h[2], b[(i >> 2) & 3].h[3]};
+        c4[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, c4[i], 0, 0, 0);
+      }
+    } else if constexpr (MODE == 0 || MODE == 2) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         if constexpr (MODE == 2) {
@@ -80,8 +87,8 @@ template <int MODE, int RD16> void run(const char* name, const uint4* src, float
   std::vector<double> clk;
   for (int i = 0; i < grid; ++i) clk.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1);     // GHz: memrealtime ticks at 100 MHz
   std::sort(clk.begin(), clk.end());
-  const double mfma_per_it = (MODE == 0 || MODE == 2) ? 16 : 8;
-  const double flop_per = (MODE == 0 || MODE == 2) ? 16.0 * 16 * 32 * 2 : 32.0 * 32 * 16 * 2;
+  const double mfma_per_it = (MODE == 0 || MODE == 2 || MODE == 4) ? 16 : 8;
+  const double flop_per = MODE == 4 ? 16.0 * 16 * 16 * 2 : (MODE == 0 || MODE == 2) ? 16.0 * 16 * 32 * 2 : 32.0 * 32 * 16 * 2;
   const double flops = (double)grid * 4 * iters * mfma_per_it * flop_per * reps;
   printf("%-44s %d wg/CU: %7.1f TFLOP/s (%.3f of 2500)  in-kernel clock median %.2f GHz\n", name, wg_per_cu, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 2.5e15, clk[clk.size() / 2]);
 }
@@ -96,6 +103,7 @@ int main() {
   for (int wg = 1; wg <= 2; ++wg) {
     run<0, 0>("16x16x32 f16, operands in registers", src, out, st, wg);
     run<1, 0>("32x32x16 f16, operands in registers", src, out, st, wg);
+    run<4, 0>("16x16x16 f16 (CDNA3 form), operands in registers", src, out, st, wg);
     run<2, 8>("16x16x32 f16 + 0.5 ds_read_b128 per MFMA", src, out, st, wg);
     run<2, 5>("16x16x32 f16 + 0.31 ds_read_b128 per MFMA", src, out, st, wg);
     run<3, 8>("32x32x16 f16 + 1 ds_read_b128 per MFMA", src, out, st, wg);
