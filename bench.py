@@ -1108,7 +1108,7 @@ def main():
             d = prof[0]
             dtp = d["variant"].split("_")[0]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-            kname = "conv_rows16pc_kernel" if d["variant"].endswith("_rows16pc") else "conv_rows16_kernel" if d["variant"].endswith("_rows16") else "conv_rows_kernel" if "_rows" in d["variant"] else "conv_mfma_kernel"
+            kname = "conv_trunk_kernel" if d["variant"].endswith("_trunk") else "conv_rows16pc_kernel" if d["variant"].endswith("_rows16pc") else "conv_rows16_kernel" if d["variant"].endswith("_rows16") else "conv_rows_kernel" if "_rows" in d["variant"] else "conv_mfma_kernel"
             roof = {"bound": "mfma", "kernel": f"{kname}<{d['variant']}> ({d['stage']})", "achieved": round(ach, 2),
                     "peak": PEAK_TFLOPS[dtp], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtp], 4),
                     # algorithmic bytes of the SAME launches the events timed: inputs, residuals and outputs once + weights once (ffp_*_profile_bytes)
