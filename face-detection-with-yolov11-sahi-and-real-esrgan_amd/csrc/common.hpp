@@ -62,7 +62,11 @@ struct DevBuf {
   void alloc(size_t bytes) {
     release();
     if (bytes == 0) bytes = 16;
-    FFP_HIP(hipMalloc(&p, bytes));
+    // FFP_ALLOC_FLAGS (experiment): 3 = hipDeviceMallocUncached for buffers of at least 1 MiB (activations, tables; MTYPE_UC: nothing of them is ever dirty in
+    // an L2, so a kernel boundary has nothing to write back — for this stream or for the one running beside it), 1 = hipDeviceMallocFinegrained
+    static const int flags = [] { const char* e = getenv("FFP_ALLOC_FLAGS"); return e ? atoi(e) : 0; }();
+    if (flags && bytes >= (1u << 20)) FFP_HIP(hipExtMallocWithFlags(&p, bytes, (unsigned)flags));
+    else FFP_HIP(hipMalloc(&p, bytes));
     n = bytes;
   }
   void ensure(size_t bytes) { if (bytes > n) alloc(bytes); }
