@@ -7,6 +7,30 @@
 #include <cstdlib>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
+__global__ void spin_lds(unsigned ticks, unsigned* sink) {          // the same with dynamic LDS (launch parameter): how many workgroups fit a CU
+  extern __shared__ unsigned lds_[];
+  lds_[threadIdx.x] = ticks;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {}
+  if (sink && lds_[threadIdx.x ^ 1] == 0xFFFFFFFFu) *sink = 1;
+}
+
+// chains with LDS: stream a = na kernels of ua us on wa workgroups, stream b = nb x ub on wb, every workgroup holding `lds` bytes
+static double chain_lds(hipStream_t a, hipStream_t b, int na, int ua, int wa, int nb, int ub, int wb, int lds, double* tb_done) {
+  CK(hipDeviceSynchronize());
+  hipEvent_t eb;
+  CK(hipEventCreate(&eb));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < (na > nb ? na : nb); ++i) {
+    if (a && i < na) hipLaunchKernelGGL(spin_lds, dim3(wa), dim3(256), lds, a, (unsigned)(ua * 100), nullptr);
+    if (b && i < nb) hipLaunchKernelGGL(spin_lds, dim3(wb), dim3(256), lds, b, (unsigned)(ub * 100), nullptr);
+  }
+  if (b) { CK(hipEventRecord(eb, b)); CK(hipEventSynchronize(eb)); }
+  *tb_done = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  CK(hipDeviceSynchronize());
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
 __global__ void spin(unsigned ticks, unsigned* sink) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {}
@@ -77,6 +101,15 @@ int main() {
     chain2(nullptr, b, 0, 0, 400, 5, wgs, &tb);
     const double tab = chain2(a, b, 100, 50, 400, 5, wgs, &tb2);
     printf("unequal %4d workgroups: A = 100 x 50 us alone %.2f ms, B = 400 x 5 us alone %.2f ms; together: all done %.2f ms, B's chain done after %.2f ms\n", wgs, ta, tb, tab, tb2);
+  }
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&spin_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  for (int lds : {80 * 1024, 40 * 1024, 16 * 1024}) {
+    double tb = 0, tb2 = 0;
+    chain_lds(a, b, 10, 50, 512, 10, 5, 200, lds, &tb);
+    const double ta = chain_lds(a, nullptr, 100, 50, 512, 0, 0, 0, lds, &tb);
+    chain_lds(nullptr, b, 0, 0, 0, 400, 5, 200, lds, &tb);
+    const double tab = chain_lds(a, b, 100, 50, 512, 400, 5, 200, lds, &tb2);
+    printf("LDS %3d KiB per workgroup: A = 100 x 50 us x 512 workgroups alone %.2f ms, B = 400 x 5 us x 200 workgroups alone %.2f ms; together: all done %.2f ms, B's chain done after %.2f ms\n", lds / 1024, ta, tb, tab, tb2);
   }
   return 0;
 }
