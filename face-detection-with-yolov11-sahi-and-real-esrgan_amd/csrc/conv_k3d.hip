@@ -439,7 +439,8 @@ template <int S, int WM, int WN, int MI, int NIW> struct K3Cfg {
     const long long items = (long long)n_tiles * a.n_nblk;
     long long per_xcd = (items + 7) / 8;
     per_xcd = (per_xcd + a.n_nblk - 1) / a.n_nblk * a.n_nblk;
-    long long ws = std::max<long long>(32 * G::OCC, (per_xcd + G::TCAP - 1) / G::TCAP);
+    static const int ws_env = [] { const char* e = getenv("FFP_K3D_WS"); return e ? atoi(e) : 0; }();      // experiment: workgroups per XCD (32 = one per CU: half of every CU's LDS stays free)
+    long long ws = std::max<long long>(ws_env > 0 ? ws_env : 32 * G::OCC, (per_xcd + G::TCAP - 1) / G::TCAP);
     ws = (ws + a.n_nblk - 1) / a.n_nblk * a.n_nblk;
     FFP_CHECK(8 * ws < (1ll << 31) && (per_xcd + ws - 1) / ws <= G::TCAP, FFP_ERR_STATE, "conv_k3d: launch geometry");
     hipLaunchKernelGGL((conv_k3d_kernel<S, WM, WN, MI, NIW>), dim3((unsigned)(8 * ws)), dim3(256), G::LDS, st, a);
